@@ -1,0 +1,107 @@
+"""GPU parity: conv_igemm (through the C ABI) vs oracle/unet3d_ref.py conv restatements."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet3d_ref as R
+
+
+def _bf16r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _rel(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+CASES = [
+    # B, F, H, W, Cin, Cout, k, stride, kind
+    (1, 4, 16, 16, 16, 32, 3, 1, 0),
+    (2, 4, 16, 16, 64, 64, 3, 1, 0),
+    (1, 2, 32, 32, 64, 128, 3, 1, 0),
+    (1, 3, 6, 10, 8, 24, 3, 1, 0),        # ragged: odd frames, non-pow2 image, masked tiles
+    (1, 4, 2, 2, 128, 128, 3, 1, 0),      # 2x2 images (tiny-config bottleneck)
+    (1, 4, 16, 16, 32, 32, 4, 2, 0),      # Downsample
+    (2, 2, 8, 8, 64, 64, 4, 2, 0),
+    (1, 4, 8, 8, 32, 32, 4, 1, 1),        # Upsample (ConvTranspose)
+    (1, 2, 4, 4, 128, 128, 4, 1, 1),
+    (1, 4, 8, 8, 48, 40, 1, 1, 0),        # pointwise
+    (1, 16, 64, 64, 64, 64, 3, 1, 0),     # north-star level-0 shape
+]
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', CASES)
+def test_conv_parity(mode, case):
+    from video_diffusion_nnx_amd import ops
+    B, Fr, H, W, Cin, Cout, k, stride, kind = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, Fr, H, W, Cin, generator=g)
+    kern = torch.randn(1, k, k, Cin, Cout, generator=g) / (k * k * Cin) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    dev = torch.device('cuda:0')
+    pw = ops.pack_conv_weights(kern.to(dev), mode)
+    stats = ops.gn_stats_zeros(B, 8, dev) if Cout % 8 == 0 else None
+    y = ops.conv_forward(x.to(dev), pw, Cout, mode=mode, bias=bias.to(dev), kind=kind, k=k, stride=stride,
+                         out_stats=stats, out_groups=8)
+    torch.cuda.synchronize()
+    xr, kr = (x, kern) if mode == 'f32' else (_bf16r(x), _bf16r(kern))
+    if kind == 1:
+        ref = R.conv_transpose_144(xr.double(), kr.double(), bias.double())
+    elif k == 1:
+        ref = R.conv_pointwise(xr.double(), kr.double()[0], bias.double())
+    else:
+        ref = R.conv_1kk(xr.double(), kr.double(), bias.double(), stride=stride)
+    assert y.shape == ref.shape
+    rel = _rel(y.cpu().double(), ref)
+    assert rel < 2e-6, f'{mode} {case}: rel {rel}'           # exact products, fp32 accumulate
+    if mode == 'bf16':                                      # and against the un-rounded fp32 reference
+        full = (R.conv_transpose_144(x.double(), kern.double(), bias.double()) if kind == 1 else
+                R.conv_pointwise(x.double(), kern.double()[0], bias.double()) if k == 1 else
+                R.conv_1kk(x.double(), kern.double(), bias.double(), stride=stride))
+        assert _rel(y.cpu().double(), full) < 8e-3
+    if stats is not None:
+        s = ops.gn_stats_reduce(stats, B, 8).cpu()
+        yg = ref.reshape(B, -1, 8, Cout // 8)
+        np.testing.assert_allclose(s[..., 0], yg.sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+        np.testing.assert_allclose(s[..., 1], (yg * yg).sum(dim=(1, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_conv_concat_and_prologue(mode):
+    """Two-pointer concat input; GroupNorm-apply * (scale+1) + shift -> SiLU prologue (Block, modules.py:171-179)."""
+    from video_diffusion_nnx_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(7)
+    B, Fr, H, W, C0, C1, Cout = 2, 4, 8, 8, 32, 16, 32
+    xa, xb = torch.randn(B, Fr, H, W, C0, generator=g), torch.randn(B, Fr, H, W, C1, generator=g)
+    kern = torch.randn(1, 3, 3, C0 + C1, Cout, generator=g) / (9 * (C0 + C1)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    pw = ops.pack_conv_weights(kern.to(dev), mode)
+    stats1 = ops.gn_stats_zeros(B, 8, dev)
+    y1 = ops.conv_forward(xa.to(dev), pw, Cout, mode=mode, bias=bias.to(dev), x1=xb.to(dev), out_stats=stats1)
+    cat = torch.cat((xa, xb), -1)
+    cr, kr = (cat, kern) if mode == 'f32' else (_bf16r(cat), _bf16r(kern))
+    ref1 = R.conv_1kk(cr.double(), kr.double(), bias.double())
+    assert _rel(y1.cpu().double(), ref1) < 2e-6
+    # second conv consumes y1 through the fused prologue
+    gamma, beta = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    ss = torch.randn(B, 2 * Cout, generator=g) * 0.3
+    kern2 = torch.randn(1, 3, 3, Cout, Cout, generator=g) / (9 * Cout) ** 0.5
+    pw2 = ops.pack_conv_weights(kern2.to(dev), mode)
+    for use_ss in (True, False):
+        y2 = ops.conv_forward(y1, pw2, Cout, mode=mode, in_stats=stats1, gamma=gamma.to(dev), beta=beta.to(dev),
+                              scale_shift=ss.to(dev) if use_ss else None)
+        h = R.group_norm(y1.cpu().double(), gamma.double(), beta.double(), 8)
+        if use_ss:
+            h = h * (ss[:, None, None, None, :Cout].double() + 1) + ss[:, None, None, None, Cout:].double()
+        h = R.silu(h)
+        if mode == 'bf16':
+            h, k2 = _bf16r(h.float()).double(), _bf16r(kern2).double()
+        else:
+            k2 = kern2.double()
+        ref2 = R.conv_1kk(h, k2, None)
+        tol = 2e-5 if mode == 'f32' else 3e-3     # bf16: rounding boundary flips of the fused activation
+        assert _rel(y2.cpu().double(), ref2) < tol, (mode, use_ss, _rel(y2.cpu().double(), ref2))

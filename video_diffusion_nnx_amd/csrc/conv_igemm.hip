@@ -1,0 +1,339 @@
+// Implicit-GEMM (1,kh,kw) convolution over channel-last video tensors on MFMA (gfx950).
+//
+// Replaces, for the new path, what XLA did for the reference's nnx.Conv / nnx.ConvTranspose calls:
+//   Block.proj (1,3,3) ............ /root/reference/modules.py:162-165,172
+//   Downsample (1,4,4)/s2 ......... /root/reference/utils.py:115-125
+//   Upsample ConvTranspose ........ /root/reference/utils.py:103-113 (4 output phases x 2x2 taps)
+//   1x1 projections ............... /root/reference/modules.py:71-91,219-222
+// and fuses the neighbouring elementwise work of Block (modules.py:171-179):
+//   prologue  = GroupNorm-apply * (scale+1) + shift -> SiLU on the INPUT as it is staged to LDS
+//   epilogue  = +bias, GroupNorm partial statistics (sum, sum^2 per (sample, group)) of the OUTPUT
+// so a Block's activation makes one HBM round trip.
+//
+// GEMM view: D[cout, pixel] = sum_{tap, cin} Wp[tap][cout][cin] * X[pixel + tap][cin].
+// A 256-thread workgroup owns 128 output pixels (NP patches of PH x PW of consecutive frames) x BC
+// output channels.  Per K tile (128 B of cin per pixel) the (F,H,W) halo tile is staged ONCE in LDS
+// (the 9 taps re-read it with shifted per-lane addresses); the weight tile of each tap streams through
+// a 2-deep register->LDS ring.  Accumulators: lane (r,q) holds channels 4q..4q+3 of pixel r (vdx_common.h).
+#include "vdx_common.h"
+#include "vdx_internal.h"
+
+namespace vdx {
+
+template <int MODE, int BC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
+    using M = Mma<MODE>;
+    constexpr int KT = M::KT;
+    constexpr int RS = ROW_STRIDE;
+    constexpr int WAVES_C = BC / 64;
+    constexpr int WAVES_P = 4 / WAVES_C;
+    constexpr int TM = 4;
+    constexpr int TN = (128 / WAVES_P) / 16;
+    constexpr int APIECES = KT / 4;                 // float4 pieces per staged pixel row
+    constexpr int WREGS = BC * 8 / 256;             // 16-byte weight pieces per thread per tap
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    const int wc = wave % WAVES_C, wpx = wave / WAVES_C;
+
+    // ---- block decode -------------------------------------------------------------------------
+    int bx = blockIdx.x;
+    const int tx = bx % P.tiles_x; bx /= P.tiles_x;
+    const int ty = bx % P.tiles_y;
+    const int fg = bx / P.tiles_y;
+    const int f0 = fg * P.NP;
+    const int b = f0 / P.F;                          // NP divides F: one sample per workgroup
+    const int c0 = blockIdx.y * BC;
+    const int ry = P.kind ? (blockIdx.z >> 1) : 0, rx = P.kind ? (blockIdx.z & 1) : 0;
+    const int KH = P.kind ? 2 : P.kh, KW = P.kind ? 2 : P.kw;
+    const int ntaps = KH * KW;
+    const int IH = (P.PH - 1) * P.stride + KH, IW = (P.PW - 1) * P.stride + KW;
+    const int oy0 = ty * P.PH, ox0 = tx * P.PW;
+    const int iy0 = oy0 * P.stride + (P.kind ? ry - 1 : -P.pad);
+    const int ix0 = ox0 * P.stride + (P.kind ? rx - 1 : -P.pad);
+    const int HPX = P.NP * IH * IW;
+    const int Cin = P.C0 + P.C1;
+    const int nchunks = P.CinPad / KT;
+
+    // ---- LDS carve (every offset a multiple of 16 bytes) ------------------------------------------
+    size_t off = 0;
+    float* chs = reinterpret_cast<float*>(smem + off); off += 2 * BC * 4;          // [2][BC] channel sum / sumsq
+    int* hp_src = reinterpret_cast<int*>(smem + off); off += ((HPX * 4 + 15) / 16) * 16;   // [HPX] global pixel or -1
+    float* coefA = nullptr; float* coefD = nullptr; float* gmean = nullptr;
+    if (P.pro) {
+        coefA = reinterpret_cast<float*>(smem + off); off += (size_t)P.CinPad * 4;
+        coefD = reinterpret_cast<float*>(smem + off); off += (size_t)P.CinPad * 4;
+        gmean = reinterpret_cast<float*>(smem + off); off += 64 * 4;               // [groups<=32][mean, rstd]
+    }
+    char* As = smem + off; off += (size_t)HPX * RS;
+    char* Ws = smem + off;                                                          // [2][BC rows]
+
+    for (int i = tid; i < 2 * BC; i += 256) chs[i] = 0.f;
+    for (int hp = tid; hp < HPX; hp += 256) {
+        const int patch = hp / (IH * IW);
+        const int r = hp - patch * (IH * IW);
+        const int iy = r / IW, ix = r - iy * IW;
+        const int gy = iy0 + iy, gx = ix0 + ix, f = f0 + patch;
+        hp_src[hp] = (f < P.NF && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W) ? ((f * P.H + gy) * P.W + gx) : -1;
+    }
+    if (P.pro) {
+        // per-channel affine of GroupNorm-apply (+ time scale/shift):  x_hat = x * a + d
+        if (tid < P.groups) {
+            const double cnt = (double)P.F * P.H * P.W * (Cin / P.groups);
+            float m, rs;
+            gn_mean_rstd(P.in_stats, b, tid, P.groups, cnt, m, rs);
+            gmean[2 * tid] = m; gmean[2 * tid + 1] = rs;
+        }
+        __syncthreads();
+        for (int c = tid; c < P.CinPad; c += 256) {
+            float a = 0.f, d = 0.f;
+            if (c < Cin) {
+                const int g = c / (Cin / P.groups);
+                const float m = gmean[2 * g], rs = gmean[2 * g + 1];
+                const float ga = P.gamma[c], be = P.beta[c];
+                float sc = 1.f, sh = 0.f;
+                if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + c] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + Cin + c]; }
+                a = rs * ga * sc;
+                d = (be - m * rs * ga) * sc + sh;
+            }
+            coefA[c] = a; coefD[c] = d;
+        }
+    }
+    __syncthreads();
+
+    // ---- per-lane activation-fragment offsets ----------------------------------------------------
+    int pixoff[TN];
+    bool pvalid[TN];
+    int gout[TN];                                    // output pixel index (into y, channel-last) or -1
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int p = wpx * (TN * 16) + tn * 16 + lp;
+        const int patch = p / (P.PH * P.PW);
+        const int r = p - patch * (P.PH * P.PW);
+        const int py = r / P.PW, px = r - py * P.PW;
+        pixoff[tn] = ((patch * IH + py * P.stride) * IW + px * P.stride) * RS + q * 16;
+        const int oy = oy0 + py, ox = ox0 + px, f = f0 + patch;
+        pvalid[tn] = (f < P.NF) && (oy < P.Ho) && (ox < P.Wo);
+        const int yy = P.kind ? (2 * oy + ry) : oy, xx = P.kind ? (2 * ox + rx) : ox;
+        gout[tn] = pvalid[tn] ? ((f * P.Hy + yy) * P.Wy + xx) : -1;
+    }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- weight staging helpers ------------------------------------------------------------------
+    uint4 wreg[WREGS];
+    const char* wbase = reinterpret_cast<const char*>(P.wp);
+    auto wload = [&](int tap, int cc) {
+        int widx = tap;
+        if (P.kind) { const int dy = tap >> 1, dx = tap & 1; widx = (2 * dy + ry) * 4 + (2 * dx + rx); }
+#pragma unroll
+        for (int k = 0; k < WREGS; ++k) {
+            const int i = tid + 256 * k;
+            const int row = i >> 3, pc = i & 7;
+            const int co = c0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (co < P.Cout)
+                v = *reinterpret_cast<const uint4*>(wbase + (((size_t)widx * P.Cout + co) * P.CinPad + (size_t)cc * KT) * M::ES + pc * 16);
+            wreg[k] = v;
+        }
+    };
+    auto wstore = [&](int buf) {
+        char* dst = Ws + (size_t)buf * BC * RS;
+#pragma unroll
+        for (int k = 0; k < WREGS; ++k) {
+            const int i = tid + 256 * k;
+            const int row = i >> 3, pc = i & 7;
+            *reinterpret_cast<uint4*>(dst + row * RS + pc * 16) = wreg[k];
+        }
+    };
+
+    // ---- main loop: K tiles of cin x taps --------------------------------------------------------
+    int buf = 0;
+    wload(0, 0);
+    for (int cc = 0; cc < nchunks; ++cc) {
+        if (cc) __syncthreads();                     // every wave is done reading the previous halo tile
+        for (int i = tid; i < HPX * APIECES; i += 256) {
+            const int hp = i / APIECES, pc = i - hp * APIECES;
+            const int c = cc * KT + pc * 4;
+            const int src = hp_src[hp];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src >= 0 && c < Cin) {
+                v = (c < P.C0) ? *reinterpret_cast<const float4*>(P.x0 + (size_t)src * P.C0 + c)
+                               : *reinterpret_cast<const float4*>(P.x1 + (size_t)src * P.C1 + (c - P.C0));
+                if (P.pro) {
+                    const float4 a = *reinterpret_cast<const float4*>(coefA + c);
+                    const float4 d = *reinterpret_cast<const float4*>(coefD + c);
+                    v.x = silu_f(fmaf(v.x, a.x, d.x)); v.y = silu_f(fmaf(v.y, a.y, d.y));
+                    v.z = silu_f(fmaf(v.z, a.z, d.z)); v.w = silu_f(fmaf(v.w, a.w, d.w));
+                }
+            }
+            M::store4(As + (size_t)hp * RS, pc * 4, v);
+        }
+        for (int tap = 0; tap < ntaps; ++tap) {
+            wstore(buf);
+            __syncthreads();
+            {   // prefetch the next weight tile while this one is consumed
+                int ntap = tap + 1, ncc = cc;
+                if (ntap == ntaps) { ntap = 0; ncc = cc + 1; }
+                if (ncc < nchunks) wload(ntap, ncc);
+            }
+            const int dy = tap / KW, dx = tap - dy * KW;
+            const int tapoff = (dy * IW + dx) * RS;
+            const char* wt = Ws + (size_t)buf * BC * RS + (wc * 64 + lp) * RS + q * 16;
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                uint4 bf[TN], af[TM];
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(As + pixoff[tn] + tapoff + ch * CHUNK_BYTES);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) af[tm] = *reinterpret_cast<const uint4*>(wt + tm * 16 * RS + ch * CHUNK_BYTES);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
+            }
+            buf ^= 1;
+        }
+    }
+
+    // ---- epilogue: bias, store, GroupNorm partial statistics --------------------------------------
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int co = c0 + wc * 64 + tm * 16 + q * 4;
+        const bool cvalid = co < P.Cout;
+        float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cvalid && P.bias) bias = *reinterpret_cast<const float4*>(P.bias + co);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), ss = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            float4 v;
+            v.x = acc[tm][tn][0] + bias.x; v.y = acc[tm][tn][1] + bias.y;
+            v.z = acc[tm][tn][2] + bias.z; v.w = acc[tm][tn][3] + bias.w;
+            if (cvalid && gout[tn] >= 0) {
+                *reinterpret_cast<float4*>(P.y + (size_t)gout[tn] * P.Cout + co) = v;
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+                ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
+            }
+        }
+        if (P.out_stats) {
+            s.x = reduce16(s.x); s.y = reduce16(s.y); s.z = reduce16(s.z); s.w = reduce16(s.w);
+            ss.x = reduce16(ss.x); ss.y = reduce16(ss.y); ss.z = reduce16(ss.z); ss.w = reduce16(ss.w);
+            if (lp == 0) {
+                const int lc = wc * 64 + tm * 16 + q * 4;
+                atomicAdd(&chs[lc + 0], s.x); atomicAdd(&chs[lc + 1], s.y);
+                atomicAdd(&chs[lc + 2], s.z); atomicAdd(&chs[lc + 3], s.w);
+                atomicAdd(&chs[BC + lc + 0], ss.x); atomicAdd(&chs[BC + lc + 1], ss.y);
+                atomicAdd(&chs[BC + lc + 2], ss.z); atomicAdd(&chs[BC + lc + 3], ss.w);
+            }
+        }
+    }
+    if (P.out_stats) {
+        __syncthreads();
+        const int cpg = P.Cout / P.out_groups;               // channels per group
+        const int g_lo = c0 / cpg;
+        const int c_hi = min(c0 + BC, P.Cout);
+        const int g_hi = (c_hi + cpg - 1) / cpg;              // groups touched by this channel tile
+        const int ng = g_hi - g_lo;
+        if (tid < 2 * ng) {
+            const int g = g_lo + (tid >> 1), which = tid & 1;
+            const int lo = max(g * cpg, c0), hi = min((g + 1) * cpg, c_hi);
+            float t = 0.f;
+            for (int c = lo; c < hi; ++c) t += chs[which * BC + (c - c0)];
+            const int slot = (blockIdx.x + blockIdx.z * 7) % GN_SLOTS;
+            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + slot) * P.out_groups + g) * 2 + which, (double)t);
+        }
+    }
+}
+
+// Flax kernel [taps][Cin][Cout] fp32  ->  packed [taps][Cout][CinPad] in the MMA element type, zero padded.
+template <int MODE>
+__global__ void pack_weights_kernel(const float* __restrict__ src, void* __restrict__ dst, int taps, int Cin, int Cout, int CinPad) {
+    const size_t n = (size_t)taps * Cout * CinPad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % CinPad);
+        const size_t r = i / CinPad;
+        const int co = (int)(r % Cout);
+        const int t = (int)(r / Cout);
+        const float v = (ci < Cin) ? src[((size_t)t * Cin + ci) * Cout + co] : 0.f;
+        if (MODE == MODE_F32) reinterpret_cast<float*>(dst)[i] = v;
+        else reinterpret_cast<__bf16*>(dst)[i] = (__bf16)v;
+    }
+}
+
+// ---- host-side launchers ----------------------------------------------------------------------------
+
+static void choose_patch(int NF, int F, int Ho, int Wo, int stride, int K, int& PH, int& PW, int& NP) {
+    int pw = 4;
+    while (pw < Wo && pw < 16) pw *= 2;
+    long best = -1;
+    PH = 128 / pw; PW = pw; NP = 1;
+    for (int np = 1; np <= 8; np *= 2) {
+        if (F % np) continue;
+        const int ph = 128 / (pw * np);
+        if (ph < 1) continue;
+        const int IH = (ph - 1) * stride + K, IW = (pw - 1) * stride + K;
+        if ((long)np * IH * IW > 400) continue;                  // keep the halo tile within the LDS budget
+        const long blocks = (long)(NF / np) * ((Ho + ph - 1) / ph) * ((Wo + pw - 1) / pw);
+        if (best < 0 || blocks < best) { best = blocks; PH = ph; PW = pw; NP = np; }
+    }
+}
+
+size_t conv_packed_bytes(int mode, int taps, int Cin, int Cout) {
+    const int KT = mode == MODE_F32 ? Mma<MODE_F32>::KT : Mma<MODE_BF16>::KT;
+    const int ES = mode == MODE_F32 ? 4 : 2;
+    const int CinPad = (Cin + KT - 1) / KT * KT;
+    return (size_t)taps * Cout * CinPad * ES;
+}
+
+int conv_cin_pad(int mode, int Cin) {
+    const int KT = mode == MODE_F32 ? Mma<MODE_F32>::KT : Mma<MODE_BF16>::KT;
+    return (Cin + KT - 1) / KT * KT;
+}
+
+hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, int Cin, int Cout, hipStream_t st) {
+    const int CinPad = conv_cin_pad(mode, Cin);
+    const size_t n = (size_t)taps * Cout * CinPad;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+    if (mode == MODE_F32) hipLaunchKernelGGL(pack_weights_kernel<MODE_F32>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CinPad);
+    else hipLaunchKernelGGL(pack_weights_kernel<MODE_BF16>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CinPad);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
+    // geometry completion
+    const int K = a.kind ? 2 : a.kh;
+    if (a.kind) { a.stride = 1; a.Ho = a.H; a.Wo = a.W; a.Hy = 2 * a.H; a.Wy = 2 * a.W; }
+    else { a.Ho = (a.H + a.stride - 1) / a.stride; a.Wo = (a.W + a.stride - 1) / a.stride; a.Hy = a.Ho; a.Wy = a.Wo; }
+    a.CinPad = conv_cin_pad(mode, a.C0 + a.C1);
+    choose_patch(a.NF, a.F, a.Ho, a.Wo, a.stride, K, a.PH, a.PW, a.NP);
+    a.tiles_y = (a.Ho + a.PH - 1) / a.PH;
+    a.tiles_x = (a.Wo + a.PW - 1) / a.PW;
+    const int BC = a.Cout <= 64 ? 64 : 128;
+    const int IH = (a.PH - 1) * a.stride + K, IW = (a.PW - 1) * a.stride + K;
+    const int HPX = a.NP * IH * IW;
+    size_t lds = 2 * BC * 4 + ((HPX * 4 + 15) / 16) * 16 + (a.pro ? (2 * a.CinPad * 4 + 64 * 4) : 0)
+               + (size_t)HPX * ROW_STRIDE + 2 * (size_t)BC * ROW_STRIDE;
+    dim3 grid((a.NF / a.NP) * a.tiles_y * a.tiles_x, (a.Cout + BC - 1) / BC, a.kind ? 4 : 1);
+#define VDX_LAUNCH_CONV(MODE_, BC_)                                                                      \
+    do {                                                                                                  \
+        auto kfn = conv_igemm_kernel<MODE_, BC_>;                                                         \
+        if (lds > 64 * 1024) {                                                                            \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            if (e != hipSuccess) return e;                                                                \
+        }                                                                                                 \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);                                             \
+    } while (0)
+    if (mode == MODE_F32) { if (BC == 64) VDX_LAUNCH_CONV(MODE_F32, 64); else VDX_LAUNCH_CONV(MODE_F32, 128); }
+    else { if (BC == 64) VDX_LAUNCH_CONV(MODE_BF16, 64); else VDX_LAUNCH_CONV(MODE_BF16, 128); }
+#undef VDX_LAUNCH_CONV
+    return hipGetLastError();
+}
+
+}  // namespace vdx

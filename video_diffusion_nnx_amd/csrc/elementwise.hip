@@ -1,0 +1,281 @@
+// HBM-bound elementwise / small-reduction kernels of the UNet (gfx950), all fp32, float4-vectorised.
+//
+//   resblock_tail ...... out = SiLU(GroupNorm(y2)) + LayerNorm_C(r)      modules.py:173-179 (Block 2) + :240-243
+//   init_conv .......... nnx.Conv(C -> D, (1,7,7)) SAME, direct form     unet3d.py:110-115,282
+//   final_conv ......... nnx.Conv(D -> out_dim, 1) pointwise             unet3d.py:251
+//   time_mlp ........... SinusoidalPosEmb -> Linear -> GELU(tanh) -> Linear (+ cond mix)   modules.py:30-45, unet3d.py:128-133,288-298
+//   resblock_ss ........ LayerNorm(Linear(SiLU(t)))  for every ResnetBlock in one launch    modules.py:202-208,233-238
+#include "vdx_common.h"
+#include "vdx_internal.h"
+
+namespace vdx {
+
+// ------------------------------------------------------------------------------------------------
+// ResnetBlock tail.  One pixel is handled by LPP lanes (LPP a power of two <= 64), each lane VPL float4.
+// ------------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void resblock_tail_kernel(TailArgs P) {
+    __shared__ float coefA[1024], coefD[1024];
+    __shared__ float gm[64];
+    const int tid = threadIdx.x;
+    const int C = P.C;
+    // a workgroup never spans samples: blockIdx.y = sample
+    const int b = blockIdx.y;
+    if (tid < P.groups) {
+        float m, rs;
+        gn_mean_rstd(P.stats, b, tid, P.groups, (double)P.pix_per_sample * (C / P.groups), m, rs);
+        gm[2 * tid] = m; gm[2 * tid + 1] = rs;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / (C / P.groups);
+        const float a = gm[2 * g + 1] * P.gn_gamma[c];
+        coefA[c] = a;
+        coefD[c] = P.gn_beta[c] - gm[2 * g] * a;
+    }
+    __syncthreads();
+    const int LPP = P.lpp;                                   // lanes per pixel
+    const int ppb = 256 / LPP;                               // pixels per workgroup pass
+    const int sub = tid % LPP, pl = tid / LPP;
+    const float invC = 1.0f / (float)C;
+    for (long pix = (long)blockIdx.x * ppb + pl; pix < P.pix_per_sample; pix += (long)gridDim.x * ppb) {
+        const size_t base = ((size_t)b * P.pix_per_sample + pix) * C;
+        float4 r[VPL];
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c = (v * LPP + sub) * 4;
+            r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) {
+                r[v] = *reinterpret_cast<const float4*>(P.r + base + c);
+                s += r[v].x + r[v].y + r[v].z + r[v].w;
+                ss += r[v].x * r[v].x + r[v].y * r[v].y + r[v].z * r[v].z + r[v].w * r[v].w;
+            }
+        }
+        for (int o = 1; o < LPP; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+        const float mean = s * invC;
+        const float var = fmaxf(ss * invC - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + NORM_EPS);
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c = (v * LPP + sub) * 4;
+            if (c < C) {
+                const float4 y = *reinterpret_cast<const float4*>(P.y2 + base + c);
+                const float4 a = *reinterpret_cast<const float4*>(coefA + c);
+                const float4 d = *reinterpret_cast<const float4*>(coefD + c);
+                const float4 lg = *reinterpret_cast<const float4*>(P.ln_gamma + c);
+                const float4 lb = *reinterpret_cast<const float4*>(P.ln_beta + c);
+                float4 o;
+                o.x = silu_f(fmaf(y.x, a.x, d.x)) + fmaf((r[v].x - mean) * rstd, lg.x, lb.x);
+                o.y = silu_f(fmaf(y.y, a.y, d.y)) + fmaf((r[v].y - mean) * rstd, lg.y, lb.y);
+                o.z = silu_f(fmaf(y.z, a.z, d.z)) + fmaf((r[v].z - mean) * rstd, lg.z, lb.z);
+                o.w = silu_f(fmaf(y.w, a.w, d.w)) + fmaf((r[v].w - mean) * rstd, lg.w, lb.w);
+                *reinterpret_cast<float4*>(P.out + base + c) = o;
+            }
+        }
+    }
+}
+
+hipError_t launch_resblock_tail(TailArgs a, hipStream_t st) {
+    const int quads = a.C / 4;
+    int lpp = 1;
+    while (lpp < quads && lpp < 64) lpp <<= 1;
+    a.lpp = lpp;
+    const int vpl = (quads + lpp - 1) / lpp;
+    const int ppb = 256 / lpp;
+    int gx = (int)std::min<long>((a.pix_per_sample + ppb - 1) / ppb, 2048);
+    dim3 grid(gx, a.batch);
+    switch (vpl) {
+        case 1: hipLaunchKernelGGL(resblock_tail_kernel<1>, grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(resblock_tail_kernel<2>, grid, dim3(256), 0, st, a); break;
+        case 3: case 4: hipLaunchKernelGGL(resblock_tail_kernel<4>, grid, dim3(256), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// init conv: x is the EXTERNAL layout [B, Cin, F, H, W]; y is channel-last [B, F, H, W, Cout].
+// One thread = one output pixel x 16 output channels; weights are wave-uniform (scalar loads).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        int B, int Cin, int F, int H, int W, int Cout, int K) {
+    extern __shared__ float tile[];                       // [Cin][16+K-1][16+K-1]
+    const int pad = K / 2, TW = 16 + K - 1;
+    const int tx = blockIdx.x % ((W + 15) / 16), ty = blockIdx.x / ((W + 15) / 16);
+    const int f = blockIdx.y % F, b = blockIdx.y / F;
+    const int cg = blockIdx.z;                            // group of 16 output channels
+    for (int i = threadIdx.x; i < Cin * TW * TW; i += 256) {
+        const int c = i / (TW * TW), r = i % (TW * TW);
+        const int gy = ty * 16 + r / TW - pad, gx = tx * 16 + r % TW - pad;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[((((size_t)b * Cin + c) * F + f) * H + gy) * W + gx];
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int px = threadIdx.x & 15, py = threadIdx.x >> 4;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    const int co0 = cg * 16;
+    for (int c = 0; c < Cin; ++c)
+        for (int ky = 0; ky < K; ++ky)
+            for (int kx = 0; kx < K; ++kx) {
+                const float v = tile[(c * TW + py + ky) * TW + px + kx];
+                const float* wr = w + ((size_t)(ky * K + kx) * Cin + c) * Cout + co0;   // Flax (kh,kw,Cin,Cout)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] = fmaf(v, (co0 + j < Cout) ? wr[j] : 0.f, acc[j]);
+            }
+    const int oy = ty * 16 + py, ox = tx * 16 + px;
+    if (oy < H && ox < W) {
+        float* o = y + ((((size_t)b * F + f) * H + oy) * W + ox) * Cout + co0;
+        if (co0 + 16 <= Cout) {
+#pragma unroll
+            for (int j = 0; j < 16; j += 4)
+                *reinterpret_cast<float4*>(o + j) = make_float4(acc[j] + bias[co0 + j], acc[j + 1] + bias[co0 + j + 1],
+                                                                 acc[j + 2] + bias[co0 + j + 2], acc[j + 3] + bias[co0 + j + 3]);
+        } else {
+            for (int j = 0; j < 16 && co0 + j < Cout; ++j) o[j] = acc[j] + bias[co0 + j];
+        }
+    }
+}
+
+hipError_t launch_init_conv(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int F, int H, int W,
+                            int Cout, int K, hipStream_t st) {
+    const int TW = 16 + K - 1;
+    dim3 grid(((W + 15) / 16) * ((H + 15) / 16), B * F, (Cout + 15) / 16);
+    hipLaunchKernelGGL(init_conv_kernel, grid, dim3(256), (size_t)Cin * TW * TW * 4, st, x, w, bias, y, B, Cin, F, H, W, Cout, K);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// final 1x1 conv D -> Cout (Cout tiny: 1 or 3).  x channel-last [npix, D]; y channel-last [npix, Cout]
+// (for Cout == 1 this is bit-identical memory to the external [B,1,F,H,W]).  LPP lanes per pixel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         long npix, int D, int Cout, int lpp) {
+    const int sub = threadIdx.x % lpp, pl = threadIdx.x / lpp, ppb = 256 / lpp;
+    for (long pix = (long)blockIdx.x * ppb + pl; pix < npix; pix += (long)gridDim.x * ppb) {
+        for (int co = 0; co < Cout; ++co) {
+            float s = 0.f;
+            for (int c = sub * 4; c < D; c += lpp * 4) {
+                const float4 v = *reinterpret_cast<const float4*>(x + (size_t)pix * D + c);
+                s += v.x * w[(size_t)c * Cout + co] + v.y * w[(size_t)(c + 1) * Cout + co]
+                   + v.z * w[(size_t)(c + 2) * Cout + co] + v.w * w[(size_t)(c + 3) * Cout + co];
+            }
+            for (int o = 1; o < lpp; o <<= 1) s += __shfl_xor(s, o);
+            if (sub == 0) y[(size_t)pix * Cout + co] = s + bias[co];
+        }
+    }
+}
+
+hipError_t launch_final_conv(const float* x, const float* w, const float* bias, float* y, long npix, int D, int Cout, hipStream_t st) {
+    int lpp = 1;
+    while (lpp * 4 < D && lpp < 16) lpp <<= 1;
+    const int ppb = 256 / lpp;
+    const int blocks = (int)std::min<long>((npix + ppb - 1) / ppb, 4096);
+    hipLaunchKernelGGL(final_conv_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, Cout, lpp);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// time MLP: one workgroup per sample.  temb[b] = [Linear2(GELU(Linear1(sinusoid(t_b)))) | cond-mix]
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+
+__global__ __launch_bounds__(256) void time_mlp_kernel(TimeMlpArgs P) {
+    extern __shared__ float sm[];                  // emb[dim] | h[time_dim]
+    float* emb = sm;
+    float* h = sm + P.dim;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int half = P.dim / 2;
+    const float tval = P.t_is_device_scalar ? (float)P.time[0] : (float)P.time[b];
+    for (int i = tid; i < half; i += 256) {
+        const float fr = expf((float)i * -(logf(10000.0f) / (float)(half - 1)));
+        const float arg = tval * fr;
+        emb[i] = sinf(arg);
+        emb[half + i] = cosf(arg);
+    }
+    __syncthreads();
+    for (int n = tid; n < P.time_dim; n += 256) {
+        float acc = P.b1[n];
+        for (int k = 0; k < P.dim; ++k) acc = fmaf(emb[k], P.w1[(size_t)k * P.time_dim + n], acc);
+        h[n] = gelu_tanh_f(acc);
+    }
+    __syncthreads();
+    float* out = P.temb + (size_t)b * P.temb_dim;
+    for (int n = tid; n < P.time_dim; n += 256) {
+        float acc = P.b2[n];
+        for (int k = 0; k < P.time_dim; ++k) acc = fmaf(h[k], P.w2[(size_t)k * P.time_dim + n], acc);
+        out[n] = acc;
+    }
+    if (P.cond_dim) {
+        const bool use_null = P.cond_mask ? (P.cond_mask[b] != 0) : (P.null_all != 0);
+        for (int n = tid; n < P.cond_dim; n += 256)
+            out[P.time_dim + n] = use_null ? P.null_cond_emb[n] : P.cond[(size_t)b * P.cond_dim + n];
+    }
+}
+
+hipError_t launch_time_mlp(const TimeMlpArgs& a, int B, hipStream_t st) {
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(B), dim3(256), (size_t)(a.dim + a.time_dim) * 4, st, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-ResnetBlock scale/shift: ss[l][b] = LayerNorm_{2c}(Linear(SiLU(temb[b])))   grid (B, nlayers)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resblock_ss_kernel(const float* __restrict__ params, const float* __restrict__ temb,
+                                                          const SsLayer* __restrict__ layers, float* __restrict__ ss_base,
+                                                          int temb_dim, int B) {
+    extern __shared__ float sm[];                  // act[temb_dim] | red[16]
+    float* act = sm;
+    float* red = sm + temb_dim;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const SsLayer L = layers[blockIdx.y];
+    for (int k = tid; k < temb_dim; k += 256) act[k] = silu_f(temb[(size_t)b * temb_dim + k]);
+    __syncthreads();
+    const float* W = params + L.w_off;
+    const float* bias = params + L.b_off;
+    const int N = L.n;                              // 2 * cout  (<= 2048)
+    float v[8];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = tid + 256 * j;
+        v[j] = 0.f;
+        if (n < N) {
+            float acc = bias[n];
+            for (int k = 0; k < temb_dim; ++k) acc = fmaf(act[k], W[(size_t)k * N + n], acc);
+            v[j] = acc; s += acc; ss += acc * acc;
+        }
+    }
+    for (int o = 1; o < 64; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = ss; }
+    __syncthreads();
+    s = red[0] + red[1] + red[2] + red[3];
+    ss = red[4] + red[5] + red[6] + red[7];
+    const float mean = s / (float)N;
+    const float var = fmaxf(ss / (float)N - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + NORM_EPS);
+    const float* g = params + L.g_off;
+    const float* be = params + L.be_off;
+    float* out = ss_base + L.out_off + (size_t)b * N;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int n = tid + 256 * j;
+        if (n < N) out[n] = fmaf((v[j] - mean) * rstd, g[n], be[n]);
+    }
+}
+
+hipError_t launch_resblock_ss(const float* params, const float* temb, const SsLayer* layers, int nlayers, float* ss_base,
+                              int temb_dim, int B, hipStream_t st) {
+    hipLaunchKernelGGL(resblock_ss_kernel, dim3(B, nlayers), dim3(256), (size_t)(temb_dim + 16) * 4, st, params, temb, layers,
+                       ss_base, temb_dim, B);
+    return hipGetLastError();
+}
+
+}  // namespace vdx

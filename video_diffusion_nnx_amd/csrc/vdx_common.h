@@ -1,0 +1,134 @@
+// Shared device-side helpers for the gfx950 (CDNA4) kernels.  Wave = 64 lanes everywhere.
+//
+// MFMA operand convention used by every GEMM-shaped kernel in this library
+// ------------------------------------------------------------------------
+// All operands are staged in LDS "K-contiguous": a row (an output channel of a weight matrix, or a
+// pixel/token of an activation matrix) holds its reduction dimension in consecutive bytes, cut in
+// 64-byte CHUNKS.  Lane l = (r = l & 15, q = l >> 4) reads the 16 bytes [16q, 16q+16) of row r of a
+// chunk with ONE ds_read_b128 for either operand:
+//   MODE_BF16: 16 B = 8 bf16 = k {8q..8q+7} of a 32-deep chunk  -> one v_mfma_f32_16x16x32_bf16
+//   MODE_F32 : 16 B = 4 f32  = k {4q..4q+3} of a 16-deep chunk  -> four v_mfma_f32_16x16x4_f32,
+//              step s pairing element s of both fragments (k = 4q+s: a permutation of the
+//              reduction order shared by A and B, so the dot product is unchanged).
+// The A operand is always the WEIGHT side (rows = output channels), the B operand the ACTIVATION
+// side (columns = pixels/tokens), so the 16x16 accumulator of lane (r, q) holds output channels
+// 4q..4q+3 (registers 0..3) of pixel r: four consecutive channels of one pixel = one float4 of a
+// channel-last tensor.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vdx {
+
+enum { MODE_F32 = 0, MODE_BF16 = 1 };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CHUNK_BYTES = 64;    // one MFMA group of K per row
+constexpr int ROW_BYTES = 128;     // K tile staged per row = 2 chunks
+constexpr int ROW_STRIDE = 160;    // LDS row stride: 16 consecutive rows x 4 lane-quads hit 16 distinct 4-bank groups
+constexpr float NORM_EPS = 1e-6f;  // Flax LayerNorm/GroupNorm epsilon
+constexpr int GN_SLOTS = 32;       // GroupNorm partial-sum slots per (sample, group): spreads f64 atomics
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+    f32x2 v = {a, b};
+    bf16x2 r = __builtin_convertvector(v, bf16x2);   // v_cvt_pk_bf16_f32 (RNE, NaN-preserving)
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+
+template <int MODE> struct Mma;
+
+template <> struct Mma<MODE_F32> {
+    static constexpr int ES = 4;                 // element bytes in LDS / packed weights
+    static constexpr int KC = 16;                // elements per 64-byte chunk
+    static constexpr int KT = 32;                // elements per staged row (2 chunks)
+    static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+    }
+    // store 4 consecutive-k values v at element offset k (multiple of 4) of an LDS row
+    static __device__ __forceinline__ void store4(char* row, int k, float4 v) {
+        *reinterpret_cast<float4*>(row + k * 4) = v;
+    }
+    static __device__ __forceinline__ void store1(char* row, int k, float v) {
+        *reinterpret_cast<float*>(row + k * 4) = v;
+    }
+};
+
+template <> struct Mma<MODE_BF16> {
+    static constexpr int ES = 2;
+    static constexpr int KC = 32;
+    static constexpr int KT = 64;
+    static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void store4(char* row, int k, float4 v) {
+        uint2 u;
+        u.x = pack_bf16x2(v.x, v.y);
+        u.y = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<uint2*>(row + k * 2) = u;
+    }
+    static __device__ __forceinline__ void store1(char* row, int k, float v) {
+        __bf16 h = (__bf16)v;
+        *reinterpret_cast<__bf16*>(row + k * 2) = h;
+    }
+};
+
+// sum over the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float reduce16(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+// sum over the 4 lanes that share (lane & 15)
+__device__ __forceinline__ float reduce_q(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float max_q(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+__device__ __forceinline__ float max16(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1));
+    v = fmaxf(v, __shfl_xor(v, 2));
+    v = fmaxf(v, __shfl_xor(v, 4));
+    v = fmaxf(v, __shfl_xor(v, 8));
+    return v;
+}
+
+// GroupNorm statistics slab: stats[(b * GN_SLOTS + slot) * groups * 2 + g * 2 + {0: sum, 1: sumsq}]
+__device__ __forceinline__ void gn_mean_rstd(const double* stats, int b, int g, int groups, double count,
+                                             float& mean, float& rstd) {
+    double s = 0.0, ss = 0.0;
+    const double* p = stats + (size_t)b * GN_SLOTS * groups * 2 + g * 2;
+    for (int k = 0; k < GN_SLOTS; ++k) {
+        s += p[(size_t)k * groups * 2];
+        ss += p[(size_t)k * groups * 2 + 1];
+    }
+    double m = s / count;
+    double var = ss / count - m * m;     // fast variance, as Flax (use_fast_variance=True)
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)NORM_EPS));
+}
+
+}  // namespace vdx
+
+#define VDX_CHECK_HIP(expr)                                                      \
+    do {                                                                         \
+        hipError_t _e = (expr);                                                  \
+        if (_e != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
