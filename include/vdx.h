@@ -80,6 +80,44 @@ typedef struct {
  * + scale/shift + SiLU; utils.py:103-125 Up/Downsample; modules.py:219-222 res_conv). */
 int vdx_conv_forward(int mode, const vdx_conv_desc* d, void* stream);
 
+/* ResnetBlock tail: out = SiLU(GroupNorm(y2; stats, gn_gamma, gn_beta)) + LayerNorm_C(r; ln_gamma, ln_beta)
+ * (reference: modules.py:173-179 for Block 2 and :240-243 `h + norm_2(res_conv(x))`).  r is res_conv(x), or x itself
+ * when the block has no res_conv.  All tensors channel-last [batch, pix_per_sample, c]. */
+int vdx_resblock_tail(const float* y2, const float* r, float* out, const double* stats, const float* gn_gamma,
+                      const float* gn_beta, int groups, const float* ln_gamma, const float* ln_beta, int c, int batch,
+                      long pix_per_sample, void* stream);
+
+/* init_conv (reference: unet3d.py:110-115,282): x EXTERNAL layout [B,Cin,F,H,W], Flax kernel (1,k,k,Cin,Cout) fp32,
+ * y channel-last [B,F,H,W,Cout]. */
+int vdx_init_conv(const float* x, const float* kernel, const float* bias, float* y, int batch, int cin, int frames,
+                  int h, int w, int cout, int k, void* stream);
+
+/* final 1x1 conv (reference: unet3d.py:251): x [npix, d] channel-last, Flax kernel (1, d, cout), y [npix, cout]. */
+int vdx_final_conv(const float* x, const float* kernel, const float* bias, float* y, long npix, int d, int cout, void* stream);
+
+/* time_mlp (reference: modules.py:30-45 SinusoidalPosEmb; unet3d.py:128-133,288 Linear-GELU-Linear; :291-298 cond mix).
+ * temb [batch, time_dim + cond_dim].  cond/null_cond_emb/cond_mask may be NULL when cond_dim == 0;
+ * cond_mask (bytes, 1 = use null_cond_emb) overrides null_all. */
+int vdx_time_mlp(const int* time, const float* w1, const float* b1, const float* w2, const float* b2, int dim,
+                 const float* cond, const float* null_cond_emb, const unsigned char* cond_mask, int null_all, int cond_dim,
+                 float* temb, int batch, void* stream);
+
+/* Multi-head self-attention + residual (reference: modules.py:247-326 inside Residual(PreNorm(EinopsToAndFrom(..)))
+ * where PreNorm is a no-op, unet3d.py:86-96 temporal / :196-208 bottleneck spatial).  x, y channel-last [B,F,H,W,C].
+ * temporal != 0: sequences over F per (b,h,w); else sequences over (h w) per (b,f).  dim_head must be 32.
+ * wqkv_packed: vdx_pack_conv_weights of the [C, 3*heads*32] matrix (q|k|v column blocks); bqkv [3*heads*32];
+ * wo_packed: packed [heads*32, C] matrix; bo [C]. */
+int vdx_attention_forward(int mode, const float* x, float* y, const void* wqkv_packed, const float* bqkv,
+                          const void* wo_packed, const float* bo, int batch, int frames, int h, int w, int c, int heads,
+                          int temporal, void* stream);
+
+/* SpatialLinearAttention + residual (reference: modules.py:64-129 inside Residual(PreNorm(..)), unet3d.py:170-178).
+ * heads must be 8, head dim 32.  wq/wk/wv_packed: packed [C,256]; wo_packed: packed [256,C].
+ * workspace: vdx_sla_workspace_bytes(mode, batch*frames, h*w, heads). */
+size_t vdx_sla_workspace_bytes(int mode, int nframes, int npix, int heads);
+int vdx_sla_forward(int mode, const float* x, float* y, const void* wq_packed, const void* wk_packed, const void* wv_packed,
+                    const void* wo_packed, void* workspace, int batch, int frames, int h, int w, int c, int heads, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,160 @@
+"""GPU parity of the non-conv UNet blocks (through the C ABI) vs oracle/unet3d_ref.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet3d_ref as R
+
+DEV = 'cuda:0'
+
+
+def _rel(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+TOL = {'f32': 2e-5, 'bf16': 1.5e-2}
+
+
+@pytest.mark.parametrize('C,B,shape', [(16, 1, (4, 6, 6)), (64, 2, (4, 16, 16)), (128, 1, (2, 8, 8)), (256, 1, (2, 4, 4)),
+                                        (512, 2, (4, 2, 2)), (1024, 1, (2, 2, 2)), (24, 1, (3, 5, 5))])
+def test_resblock_tail(C, B, shape):
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(C)
+    y2 = torch.randn(B, *shape, C, generator=g) * 2 + 0.5
+    r = torch.randn(B, *shape, C, generator=g)
+    gg, gb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    lg, lb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    # statistics slab as the conv epilogue would leave it: everything in slot 0
+    yg = y2.double().reshape(B, -1, 8, C // 8)
+    stats = torch.zeros(B, 32, 8, 2, dtype=torch.float64)
+    stats[:, 0, :, 0] = yg.sum(dim=(1, 3)); stats[:, 0, :, 1] = (yg * yg).sum(dim=(1, 3))
+    out = ops.resblock_tail(y2.to(DEV), r.to(DEV), stats.reshape(-1).to(DEV), gg.to(DEV), gb.to(DEV), lg.to(DEV), lb.to(DEV))
+    ref = R.silu(R.group_norm(y2.double(), gg.double(), gb.double(), 8)) + R.layer_norm(r.double(), lg.double(), lb.double())
+    assert _rel(out.cpu().double(), ref) < 2e-6
+
+
+@pytest.mark.parametrize('Cin,D,k', [(1, 64, 7), (3, 16, 7), (3, 40, 3)])
+def test_init_conv(Cin, D, k):
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, Cin, 3, 20, 12, generator=g)
+    kern = torch.randn(1, k, k, Cin, D, generator=g) / k
+    bias = torch.randn(D, generator=g)
+    y = ops.init_conv(x.to(DEV), kern.to(DEV), bias.to(DEV))
+    ref = R.conv_1kk(x.double().permute(0, 2, 3, 4, 1), kern.double(), bias.double())
+    assert _rel(y.cpu().double(), ref) < 2e-6
+
+
+@pytest.mark.parametrize('D,Cout', [(64, 1), (16, 3), (32, 2)])
+def test_final_conv(D, Cout):
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, 3, 7, 5, D, generator=g)
+    kern = torch.randn(1, D, Cout, generator=g)
+    bias = torch.randn(Cout, generator=g)
+    y = ops.final_conv(x.to(DEV), kern.to(DEV), bias.to(DEV))
+    assert _rel(y.cpu().double(), R.conv_pointwise(x.double(), kern.double(), bias.double())) < 2e-6
+
+
+@pytest.mark.parametrize('dim,cond_dim', [(64, 0), (16, 32), (32, 768)])
+def test_time_mlp(dim, cond_dim):
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B = 5
+    t = torch.tensor([0, 1, 437, 998, 999])
+    w1, b1 = torch.randn(dim, 4 * dim, generator=g) / dim ** 0.5, torch.randn(4 * dim, generator=g) * 0.1
+    w2, b2 = torch.randn(4 * dim, 4 * dim, generator=g) / (4 * dim) ** 0.5, torch.randn(4 * dim, generator=g) * 0.1
+    cond = torch.randn(B, cond_dim, generator=g) if cond_dim else None
+    null = torch.randn(1, cond_dim, generator=g) if cond_dim else None
+    mask = torch.tensor([0, 1, 0, 1, 1], dtype=torch.bool) if cond_dim else None
+    temb = ops.time_mlp(t.to(DEV), w1.to(DEV), b1.to(DEV), w2.to(DEV), b2.to(DEV),
+                        cond=None if cond is None else cond.to(DEV), null_cond_emb=None if null is None else null.to(DEV),
+                        cond_mask=None if mask is None else mask.to(DEV))
+    e = R.sinusoidal_pos_emb(t, dim, torch.float64)
+    ref = R.gelu_tanh(e @ w1.double() + b1.double()) @ w2.double() + b2.double()
+    if cond_dim:
+        ref = torch.cat((ref, torch.where(mask[:, None], null.double(), cond.double())), -1)
+    # fp32 sin/cos of arguments up to ~1e3 rad: absolute error ~6e-5 in the embedding
+    assert _rel(temb.cpu().double(), ref) < 2e-4
+
+
+def _mha_params(C, heads, g):
+    p = {}
+    for n in ('q', 'k', 'v'):
+        p[f'a.{n}.kernel'] = torch.randn(C, heads, 32, generator=g) / C ** 0.5 * 2
+        p[f'a.{n}.bias'] = torch.randn(heads, 32, generator=g) * 0.2
+    p['a.out.kernel'] = torch.randn(heads, 32, C, generator=g) / (heads * 32) ** 0.5
+    p['a.out.bias'] = torch.randn(C, generator=g) * 0.2
+    return p
+
+
+ATTN_CASES = [
+    # B, F, H, W, C, heads, temporal
+    (1, 16, 8, 8, 64, 8, True),
+    (2, 10, 4, 6, 32, 8, True),       # F = 10 (YAML config): padded keys are masked
+    (1, 4, 2, 2, 128, 8, True),
+    (1, 16, 2, 2, 512, 8, True),
+    (1, 32, 3, 3, 16, 4, True),
+    (1, 3, 8, 8, 512, 8, False),      # bottleneck spatial attention: 64 tokens
+    (2, 4, 2, 2, 128, 8, False),      # 4 tokens
+    (1, 2, 4, 4, 256, 8, False),
+    (1, 2, 5, 5, 64, 8, False),       # 25 tokens -> LP 32
+]
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', ATTN_CASES)
+def test_attention(mode, case):
+    from video_diffusion_nnx_amd import ops
+    B, Fr, H, W, C, heads, temporal = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(B, Fr, H, W, C, generator=g)
+    p = _mha_params(C, heads, g)
+    packed = ops.pack_mha(*[(p[f'a.{n}.kernel'].to(DEV), p[f'a.{n}.bias'].to(DEV)) for n in ('q', 'k', 'v', 'out')], mode)
+    y = ops.attention_forward(x.to(DEV), packed, heads, temporal, mode)
+    pd = {k: v.double() for k, v in p.items()}
+    xd = x.double()
+    if temporal:
+        xt = xd.permute(0, 2, 3, 1, 4).reshape(B, H * W, Fr, C)
+        o = R.multihead_attention(pd, 'a', xt, 32).reshape(B, H, W, Fr, C).permute(0, 3, 1, 2, 4)
+    else:
+        o = R.multihead_attention(pd, 'a', xd.reshape(B, Fr, H * W, C), 32).reshape(B, Fr, H, W, C)
+    ref = o + xd
+    rel = _rel((y.cpu().double() - xd), o)          # error of the attention branch itself, not hidden by the residual
+    assert rel < TOL[mode], (mode, case, rel)
+    assert _rel(y.cpu().double(), ref) < TOL[mode]
+
+
+SLA_CASES = [
+    # B, F, H, W, C
+    (1, 2, 16, 16, 64),
+    (1, 2, 64, 64, 64),       # N = 4096: 8 chunks of 8 sub-tiles, online softmax rescale path
+    (2, 3, 8, 8, 128),
+    (1, 4, 2, 2, 512),        # N = 4 (single ragged tile)
+    (1, 2, 5, 7, 16),         # N = 35 ragged
+    (1, 1, 24, 24, 256),      # N = 576: 9 tiles -> 2 chunks, second ragged
+]
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', SLA_CASES)
+def test_sla(mode, case):
+    from video_diffusion_nnx_amd import ops
+    B, Fr, H, W, C = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Fr, H, W, C, generator=g)
+    p = {f'a.{n}.kernel': torch.randn(1, C, 256, generator=g) / C ** 0.5 * 3 for n in ('q', 'k', 'v')}
+    p['a.to_out.kernel'] = torch.randn(1, 256, C, generator=g) / 16
+    # spike some k logits so the running max jumps between sub-tiles (forces the rescale branch)
+    x[:, :, H // 2, W // 2] *= 6
+    y = ops.sla_forward(x.to(DEV), p['a.q.kernel'].to(DEV), p['a.k.kernel'].to(DEV), p['a.v.kernel'].to(DEV),
+                        p['a.to_out.kernel'].to(DEV), 8, mode)
+    o = R.spatial_linear_attention({k: v.double() for k, v in p.items()}, 'a', x.double(), 8)
+    rel = _rel(y.cpu().double() - x.double(), o)
+    assert rel < TOL[mode], (mode, case, rel)

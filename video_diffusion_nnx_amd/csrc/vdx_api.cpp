@@ -1,6 +1,7 @@
 // extern "C" surface of libvdx.so: argument validation + dispatch to the kernel launchers.
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 #include "vdx_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -63,6 +64,83 @@ int vdx_conv_forward(int mode, const vdx_conv_desc* d, void* stream) {
         a.out_stats = d->out_stats; a.out_groups = d->out_groups;
     }
     VDX_HIP(vdx::launch_conv(mode, a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_resblock_tail(const float* y2, const float* r, float* out, const double* stats, const float* gn_gamma,
+                      const float* gn_beta, int groups, const float* ln_gamma, const float* ln_beta, int c, int batch,
+                      long pix_per_sample, void* stream) {
+    if (!y2 || !r || !out || !stats || !gn_gamma || !gn_beta || !ln_gamma || !ln_beta) VDX_FAIL(VDX_ERR_INVALID, "tail: null tensor");
+    if (c % 4 || c > 1024 || groups <= 0 || groups > 32 || c % groups) VDX_FAIL(VDX_ERR_INVALID, "tail: bad channels/groups");
+    vdx::TailArgs a;
+    memset(&a, 0, sizeof(a));
+    a.y2 = y2; a.r = r; a.out = out; a.stats = stats; a.gn_gamma = gn_gamma; a.gn_beta = gn_beta; a.groups = groups;
+    a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.C = c; a.batch = batch; a.pix_per_sample = pix_per_sample;
+    VDX_HIP(vdx::launch_resblock_tail(a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_init_conv(const float* x, const float* kernel, const float* bias, float* y, int batch, int cin, int frames,
+                  int h, int w, int cout, int k, void* stream) {
+    if (!x || !kernel || !bias || !y) VDX_FAIL(VDX_ERR_INVALID, "init_conv: null tensor");
+    if (k < 1 || k > 15 || !(k & 1) || cin < 1 || cin > 8) VDX_FAIL(VDX_ERR_INVALID, "init_conv: bad kernel size / channels");
+    VDX_HIP(vdx::launch_init_conv(x, kernel, bias, y, batch, cin, frames, h, w, cout, k, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_final_conv(const float* x, const float* kernel, const float* bias, float* y, long npix, int d, int cout, void* stream) {
+    if (!x || !kernel || !bias || !y || d % 4) VDX_FAIL(VDX_ERR_INVALID, "final_conv: bad argument");
+    VDX_HIP(vdx::launch_final_conv(x, kernel, bias, y, npix, d, cout, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_time_mlp(const int* time, const float* w1, const float* b1, const float* w2, const float* b2, int dim,
+                 const float* cond, const float* null_cond_emb, const unsigned char* cond_mask, int null_all, int cond_dim,
+                 float* temb, int batch, void* stream) {
+    if (!time || !w1 || !b1 || !w2 || !b2 || !temb || dim < 4 || (dim & 1)) VDX_FAIL(VDX_ERR_INVALID, "time_mlp: bad argument");
+    if (cond_dim && (!cond || !null_cond_emb)) VDX_FAIL(VDX_ERR_INVALID, "time_mlp: cond missing");
+    vdx::TimeMlpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.time = time; a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2; a.dim = dim; a.time_dim = 4 * dim;
+    a.cond = cond; a.null_cond_emb = null_cond_emb; a.cond_mask = cond_mask; a.null_all = null_all; a.cond_dim = cond_dim;
+    a.temb = temb; a.temb_dim = 4 * dim + cond_dim;
+    VDX_HIP(vdx::launch_time_mlp(a, batch, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_attention_forward(int mode, const float* x, float* y, const void* wqkv_packed, const float* bqkv,
+                          const void* wo_packed, const float* bo, int batch, int frames, int h, int w, int c, int heads,
+                          int temporal, void* stream) {
+    if (!x || !y || !wqkv_packed || !bqkv || !wo_packed || !bo) VDX_FAIL(VDX_ERR_INVALID, "attention: null tensor");
+    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
+    if (c % 4 || c > 512 || heads < 1) VDX_FAIL(VDX_ERR_INVALID, "attention: C must be a multiple of 4 and <= 512");
+    vdx::AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y; a.wqkv = wqkv_packed; a.bqkv = bqkv; a.wo = wo_packed; a.bo = bo; a.C = c; a.heads = heads;
+    a.scale = 1.0f / sqrtf(32.0f);
+    const long hw = (long)h * w;
+    if (temporal) {
+        a.L = frames; a.nseq = (long)batch * hw; a.inner = hw; a.inner_stride = c; a.outer_stride = (long)frames * hw * c; a.tok_stride = hw * c;
+    } else {
+        a.L = (int)hw; a.nseq = (long)batch * frames; a.inner = 1; a.inner_stride = 0; a.outer_stride = hw * c; a.tok_stride = c;
+    }
+    if (a.L > 64) VDX_FAIL(VDX_ERR_INVALID, "attention: more than 64 tokens per sequence is not supported");
+    VDX_HIP(vdx::launch_attention(mode, a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+size_t vdx_sla_workspace_bytes(int mode, int nframes, int npix, int heads) { return vdx::sla_workspace_bytes(mode, nframes, npix, heads); }
+
+int vdx_sla_forward(int mode, const float* x, float* y, const void* wq_packed, const void* wk_packed, const void* wv_packed,
+                    const void* wo_packed, void* workspace, int batch, int frames, int h, int w, int c, int heads, void* stream) {
+    if (!x || !y || !wq_packed || !wk_packed || !wv_packed || !wo_packed || !workspace) VDX_FAIL(VDX_ERR_INVALID, "sla: null tensor");
+    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
+    if (heads != 8 || c % 4 || c > 512) VDX_FAIL(VDX_ERR_INVALID, "sla: needs 8 heads, C multiple of 4 and <= 512");
+    vdx::SlaArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.y = y; a.wq = wq_packed; a.wk = wk_packed; a.wv = wv_packed; a.wo = wo_packed; a.workspace = workspace;
+    a.C = c; a.heads = heads; a.NF = batch * frames; a.N = h * w;
+    VDX_HIP(vdx::launch_sla(mode, a, (hipStream_t)stream));
     return VDX_OK;
 }
 

@@ -56,3 +56,70 @@ def conv_forward(x0, packed_w, cout, *, mode, bias=None, x1=None, kind=0, k=3, s
     d.out_stats, d.out_groups = L.ptr(out_stats), out_groups
     L.check(L.vdx_conv_forward(_mode(mode), C.byref(d), L.stream_ptr()))
     return y
+
+
+def resblock_tail(y2, r, stats, gn_gamma, gn_beta, ln_gamma, ln_beta, groups=8):
+    B, C = y2.shape[0], y2.shape[-1]
+    pix = y2.numel() // (B * C)
+    out = torch.empty_like(y2)
+    L.check(L.vdx_resblock_tail(L.ptr(y2), L.ptr(r), L.ptr(out), L.ptr(stats), L.ptr(gn_gamma), L.ptr(gn_beta), groups,
+                                L.ptr(ln_gamma), L.ptr(ln_beta), C, B, pix, L.stream_ptr()))
+    return out
+
+
+def init_conv(x, kernel, bias):
+    """x [B,C,F,H,W] (external layout); kernel Flax (1,k,k,C,D) -> [B,F,H,W,D]."""
+    B, Cin, Fr, H, W = x.shape
+    k, cout = kernel.shape[1], kernel.shape[-1]
+    y = torch.empty(B, Fr, H, W, cout, dtype=torch.float32, device=x.device)
+    L.check(L.vdx_init_conv(L.ptr(x), L.ptr(kernel.contiguous()), L.ptr(bias), L.ptr(y), B, Cin, Fr, H, W, cout, k, L.stream_ptr()))
+    return y
+
+
+def final_conv(x, kernel, bias):
+    d, cout = kernel.shape[-2], kernel.shape[-1]
+    npix = x.numel() // d
+    y = torch.empty(*x.shape[:-1], cout, dtype=torch.float32, device=x.device)
+    L.check(L.vdx_final_conv(L.ptr(x), L.ptr(kernel.contiguous()), L.ptr(bias), L.ptr(y), npix, d, cout, L.stream_ptr()))
+    return y
+
+
+def time_mlp(time, w1, b1, w2, b2, cond=None, null_cond_emb=None, cond_mask=None, null_all=False):
+    B, dim = time.shape[0], w1.shape[0]
+    cond_dim = 0 if cond is None else cond.shape[-1]
+    temb = torch.empty(B, 4 * dim + cond_dim, dtype=torch.float32, device=w1.device)
+    t32 = time.to(torch.int32).contiguous()
+    cm = None if cond_mask is None else cond_mask.to(torch.uint8).contiguous()
+    L.check(L.vdx_time_mlp(L.ptr(t32), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), dim, L.ptr(cond), L.ptr(null_cond_emb),
+                           L.ptr(cm), int(null_all), cond_dim, L.ptr(temb), B, L.stream_ptr()))
+    return temb
+
+
+def pack_mha(pq, pk, pv, po, mode):
+    """pq/pk/pv: (kernel (C,H,D), bias (H,D)); po: (kernel (H,D,C), bias (C))."""
+    C_ = pq[0].shape[0]
+    wqkv = torch.cat([p[0].reshape(C_, -1) for p in (pq, pk, pv)], dim=1).contiguous()
+    bqkv = torch.cat([p[1].reshape(-1) for p in (pq, pk, pv)]).contiguous()
+    wo = po[0].reshape(-1, C_).contiguous()
+    return pack_conv_weights(wqkv, mode), bqkv, pack_conv_weights(wo, mode), po[1].contiguous()
+
+
+def attention_forward(x, packed, heads, temporal, mode):
+    B, Fr, H, W, C_ = x.shape
+    y = torch.empty_like(x)
+    wqkv, bqkv, wo, bo = packed
+    L.check(L.vdx_attention_forward(_mode(mode), L.ptr(x), L.ptr(y), L.ptr(wqkv), L.ptr(bqkv), L.ptr(wo), L.ptr(bo),
+                                    B, Fr, H, W, C_, heads, int(temporal), L.stream_ptr()))
+    return y
+
+
+def sla_forward(x, wq, wk, wv, wo, heads, mode):
+    """wq/wk/wv: Flax (1, C, 256); wo: (1, 256, C)."""
+    B, Fr, H, W, C_ = x.shape
+    m = _mode(mode)
+    y = torch.empty_like(x)
+    ws = torch.empty(L.vdx_sla_workspace_bytes(m, B * Fr, H * W, heads), dtype=torch.uint8, device=x.device)
+    pk = [pack_conv_weights(t, mode) for t in (wq, wk, wv, wo)]
+    L.check(L.vdx_sla_forward(m, L.ptr(x), L.ptr(y), L.ptr(pk[0]), L.ptr(pk[1]), L.ptr(pk[2]), L.ptr(pk[3]), L.ptr(ws),
+                              B, Fr, H, W, C_, heads, L.stream_ptr()))
+    return y
