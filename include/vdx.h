@@ -118,6 +118,56 @@ size_t vdx_sla_workspace_bytes(int mode, int nframes, int npix, int heads);
 int vdx_sla_forward(int mode, const float* x, float* y, const void* wq_packed, const void* wk_packed, const void* wv_packed,
                     const void* wo_packed, void* workspace, int batch, int frames, int h, int w, int c, int heads, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Network-level entry points.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Mirror of the reference constructors' arguments that shape the device work:
+ * Unet3D(dim, rngs, dim_mults, cond_dim, out_dim, channels, attn_heads, attn_dim_head, use_bert_text_cond,
+ *        init_dim, init_kernel_size, use_sparse_linear_attn, block_type, resnet_groups)   unet3d.py:58-75
+ * GaussianDiffusion(image_size, num_frames, ...)                                          gaussian_diffusion.py:53-65
+ * (use_bert_text_cond is resolved by the host to cond_dim = 768; 0 means "no conditioning"). */
+typedef struct {
+    int dim;
+    int n_mults; int dim_mults[8];
+    int channels;
+    int out_dim;                 /* 0 = channels */
+    int cond_dim;                /* 0 = none */
+    int attn_heads, attn_dim_head;
+    int init_dim;                /* 0 = dim */
+    int init_kernel_size;
+    int use_sparse_linear_attn;
+    int resnet_groups;
+    int image_size, num_frames;
+    int mode;                    /* vdx_mode */
+} vdx_config;
+
+typedef struct vdx_handle vdx_handle;
+
+int vdx_create(const vdx_config* cfg, vdx_handle** out);
+void vdx_destroy(vdx_handle* h);
+
+/* Flat fp32 parameter buffer layout (names = nnx state-tree paths, shapes = Flax shapes). */
+int vdx_param_count(const vdx_handle* h);
+long vdx_param_total(const vdx_handle* h);                       /* floats in the flat buffer */
+int vdx_param_info(const vdx_handle* h, int index, char* name, int name_cap, int* ndim, long shape[6], long* offset);
+
+/* Derived (packed) weights in the MFMA staging layout; re-run after every parameter update. */
+size_t vdx_packed_bytes(const vdx_handle* h);
+int vdx_pack_params(const vdx_handle* h, const float* params, void* packed, void* stream);
+
+/* Activation workspace for a batch; every intermediate keeps its own slot (inspectable for parity tests). */
+size_t vdx_workspace_bytes(const vdx_handle* h, int batch);
+int vdx_slot_count(const vdx_handle* h);
+int vdx_slot_info(const vdx_handle* h, int index, char* name, int name_cap, long* floats_per_sample, long* float_offset_per_sample);
+
+/* Unet3D.__call__ (reference: unet3d.py:262-387).  x [B,C,F,H,W]; time [B] int32 (device); cond [B,cond_dim] or NULL;
+ * cond_mask [B] bytes (1 = replace by null_cond_emb) or NULL, in which case null_all selects all/none
+ * (null_cond_prob 1 / 0); out channel-LAST [B,F,H,W,out_dim] (unet3d.py:387). */
+int vdx_unet_forward(const vdx_handle* h, const float* params, const void* packed, const float* x, const int* time,
+                     const float* cond, const unsigned char* cond_mask, int null_all, float* out, void* workspace,
+                     size_t workspace_bytes, int batch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

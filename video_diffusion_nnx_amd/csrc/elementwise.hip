@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void resblock_ss_kernel(const float* __restric
     const float rstd = rsqrtf(var + NORM_EPS);
     const float* g = params + L.g_off;
     const float* be = params + L.be_off;
-    float* out = ss_base + L.out_off + (size_t)b * N;
+    float* out = ss_base + (size_t)L.out_off * B + (size_t)b * N;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int n = tid + 256 * j;

@@ -1,0 +1,49 @@
+// Host-side model description (non-ABI).
+#pragma once
+#include <string>
+#include <vector>
+#include "vdx_internal.h"
+
+namespace vdx {
+
+struct ParamInfo { std::string name; int ndim; long shape[6]; long offset; long numel; };
+struct Slot { std::string name; long floats_per_sample; long offset_per_sample; };
+
+struct ResP {
+    std::string name;
+    int cin = 0, cout = 0; bool has_mlp = false, has_res = false; int ss_index = -1;
+    long mlp_w = 0, mlp_b = 0, n1_s, n1_b, b1_w, b1_b, b1_gs, b1_gb, b2_w, b2_b, b2_gs, b2_gb, rc_w, rc_b, n2_s, n2_b;   // float offsets
+    size_t pk_b1, pk_b2, pk_rc;                                                                               // packed byte offsets
+    int s_y1, s_y2, s_rc, s_out, st1, st2;                                                                    // workspace slots / stats slabs
+};
+struct AttnP { std::string name; int C; long norm_s, norm_b, w[3], b[3], o_w, o_b; size_t pk_qkv, pk_bqkv, pk_o; };
+struct SlaP { std::string name; int C; long norm_s, norm_b, w[3], o_w; size_t pk[3], pk_o; };
+struct Level {
+    int cin, cout, lvl; ResP res0, res1; bool has_sla; SlaP sla; AttnP attn; bool has_resample; long rs_w, rs_b; size_t pk_rs;
+    int s_sla, s_attn, s_rs;
+};
+
+struct Model {
+    vdx_config cfg;
+    int mode, init_dim, out_dim, time_dim, temb_dim;
+    std::vector<ParamInfo> params; long param_total = 0;
+    size_t packed_bytes = 0;
+    std::vector<Slot> slots; long act_floats_per_sample = 0;
+    std::vector<SsLayer> ss_layers; long ss_floats_per_sample = 0; SsLayer* d_ss_layers = nullptr;
+    int n_stats = 0;
+    size_t sla_ws_bytes_per_sample = 0;
+    long rel_pos_emb, init_w, init_b, t_w1, t_b1, t_w2, t_b2, null_cond, fin_w, fin_b;
+    AttnP init_attn, mid_sattn, mid_tattn;
+    ResP mid1, mid2, fin;
+    std::vector<Level> downs, ups;
+    int s_init, s_init_attn, s_mid_sattn, s_mid_tattn;
+};
+
+int model_build(Model* m);
+size_t model_workspace_bytes(const Model* m, int B);
+hipError_t model_pack(const Model* m, const float* params, void* packed, hipStream_t st);
+int model_forward(const Model* m, const float* params, const void* packed, const float* x, const int* time,
+                  const float* cond, const unsigned char* cond_mask, int null_all, float* out, void* workspace,
+                  size_t workspace_bytes, int B, hipStream_t st);
+
+}  // namespace vdx

@@ -3,6 +3,9 @@
 #include <string.h>
 #include <math.h>
 #include "vdx_internal.h"
+#include "model.h"
+
+struct vdx_handle { vdx::Model model; };
 
 static thread_local char g_err[512] = "";
 
@@ -142,6 +145,75 @@ int vdx_sla_forward(int mode, const float* x, float* y, const void* wq_packed, c
     a.C = c; a.heads = heads; a.NF = batch * frames; a.N = h * w;
     VDX_HIP(vdx::launch_sla(mode, a, (hipStream_t)stream));
     return VDX_OK;
+}
+
+int vdx_create(const vdx_config* cfg, vdx_handle** out) {
+    if (!cfg || !out) VDX_FAIL(VDX_ERR_INVALID, "create: null argument");
+    if (cfg->mode != VDX_MODE_F32 && cfg->mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
+    vdx_handle* h = new vdx_handle();
+    h->model.cfg = *cfg;
+    int rc = vdx::model_build(&h->model);
+    if (rc != VDX_OK) { delete h; return rc; }
+    // the only device memory the handle owns: the small ResnetBlock time-MLP table
+    const size_t tb = h->model.ss_layers.size() * sizeof(vdx::SsLayer);
+    if (tb) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0) {
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->model.d_ss_layers), tb);
+            if (e == hipSuccess) e = hipMemcpy(h->model.d_ss_layers, h->model.ss_layers.data(), tb, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { delete h; return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); }
+        }   // without a device the handle still serves the layout queries (CPU-side tests)
+    }
+    *out = h;
+    return VDX_OK;
+}
+
+void vdx_destroy(vdx_handle* h) {
+    if (!h) return;
+    if (h->model.d_ss_layers) (void)hipFree(h->model.d_ss_layers);
+    delete h;
+}
+
+int vdx_param_count(const vdx_handle* h) { return h ? (int)h->model.params.size() : 0; }
+long vdx_param_total(const vdx_handle* h) { return h ? h->model.param_total : 0; }
+
+int vdx_param_info(const vdx_handle* h, int index, char* name, int name_cap, int* ndim, long shape[6], long* offset) {
+    if (!h || index < 0 || index >= (int)h->model.params.size()) VDX_FAIL(VDX_ERR_INVALID, "param_info: bad index");
+    const vdx::ParamInfo& p = h->model.params[index];
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", p.name.c_str());
+    if (ndim) *ndim = p.ndim;
+    if (shape) for (int i = 0; i < 6; ++i) shape[i] = i < p.ndim ? p.shape[i] : 1;
+    if (offset) *offset = p.offset;
+    return VDX_OK;
+}
+
+size_t vdx_packed_bytes(const vdx_handle* h) { return h ? h->model.packed_bytes : 0; }
+
+int vdx_pack_params(const vdx_handle* h, const float* params, void* packed, void* stream) {
+    if (!h || !params || !packed) VDX_FAIL(VDX_ERR_INVALID, "pack_params: null argument");
+    VDX_HIP(vdx::model_pack(&h->model, params, packed, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+size_t vdx_workspace_bytes(const vdx_handle* h, int batch) { return h ? vdx::model_workspace_bytes(&h->model, batch) : 0; }
+int vdx_slot_count(const vdx_handle* h) { return h ? (int)h->model.slots.size() : 0; }
+
+int vdx_slot_info(const vdx_handle* h, int index, char* name, int name_cap, long* floats_per_sample, long* float_offset_per_sample) {
+    if (!h || index < 0 || index >= (int)h->model.slots.size()) VDX_FAIL(VDX_ERR_INVALID, "slot_info: bad index");
+    const vdx::Slot& s = h->model.slots[index];
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", s.name.c_str());
+    if (floats_per_sample) *floats_per_sample = s.floats_per_sample;
+    if (float_offset_per_sample) *float_offset_per_sample = s.offset_per_sample;
+    return VDX_OK;
+}
+
+int vdx_unet_forward(const vdx_handle* h, const float* params, const void* packed, const float* x, const int* time,
+                     const float* cond, const unsigned char* cond_mask, int null_all, float* out, void* workspace,
+                     size_t workspace_bytes, int batch, void* stream) {
+    if (!h || !params || !packed || !x || !time || !out || !workspace) VDX_FAIL(VDX_ERR_INVALID, "unet_forward: null argument");
+    if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "unet_forward: handle was created without a GPU");
+    return vdx::model_forward(&h->model, params, packed, x, time, cond, cond_mask, null_all, out, workspace, workspace_bytes, batch,
+                              (hipStream_t)stream);
 }
 
 }  // extern "C"
