@@ -1,0 +1,233 @@
+"""bench.py -- denoised frames/sec of the DDPM sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is ONE reverse-diffusion step (Unet3D forward + p_sample) over the per-GPU batch, replayed from a hipGraph.
+Workload = BASELINE.json configs[1] ("config_v2_2 Unet3D dim=64, 16-frame 64x64, 1000-step p_sample_loop bf16"),
+synthetic x_T ~ Philox N(0,1), random-init weights.  metric value = N * B * F / (T * seconds_per_step).
+Sampling is batch-parallel (reference gaussian_diffusion.py:290-301): ranks are independent, no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T_STEPS = 1000
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense peaks, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_layers(dim, mults, frames, size, batch):
+    """Every conv_igemm launch of one UNet forward: (Cin, Cout, H, taps, out_pixels_per_sample_frame, kind)."""
+    dims = [dim] + [dim * m for m in mults]
+    nl = len(mults)
+    L = []
+
+    def res(cin, cout, s):
+        L.append((cin, cout, s, 9, 'c3'))
+        L.append((cout, cout, s, 9, 'c3p'))
+        if cin != cout:
+            L.append((cin, cout, s, 1, 'c1'))
+    for i in range(nl):
+        s = size >> i
+        res(dims[i], dims[i + 1], s); res(dims[i + 1], dims[i + 1], s)
+        if i < nl - 1:
+            L.append((dims[i + 1], dims[i + 1], s, 16, 'down'))
+    s = size >> (nl - 1)
+    res(dims[nl], dims[nl], s); res(dims[nl], dims[nl], s)
+    for i in range(nl):
+        din, dout = dims[nl - 1 - i], dims[nl - i]
+        s = size >> (nl - 1 - i)
+        res(2 * dout, din, s); res(din, din, s)
+        if i < nl - 1:
+            L.append((din, din, s, 16, 'up'))
+    res(2 * dim, dim, size)
+    return L
+
+
+def conv_flops(layer, frames, batch):
+    cin, cout, s, taps, kind = layer
+    if kind == 'down':
+        pix = (s // 2) ** 2
+        return 2.0 * batch * frames * pix * cin * cout * 16
+    if kind == 'up':
+        return 2.0 * batch * frames * (2 * s) ** 2 * cin * cout * 4          # 4 effective taps per output
+    return 2.0 * batch * frames * s * s * cin * cout * taps
+
+
+def time_conv_kernels(unet, frames, size, batch, mode, reps=5):
+    """Roofline leg: replays every conv_igemm launch shape of one forward standalone, HIP events on the launch stream."""
+    from video_diffusion_nnx_amd import ops
+    dev = unet.device
+    per_symbol = {}
+    st = torch.cuda.current_stream(dev)
+    for layer in conv_layers(unet.dim, unet.dim_mults, frames, size, batch):
+        cin, cout, s, taps, kind = layer
+        k = {9: 3, 1: 1, 16: 4}[taps]
+        x = torch.randn(batch, frames, s, s, cin, device=dev)
+        w = torch.randn(1, k, k, cin, cout, device=dev) / (taps * cin) ** 0.5
+        pw = ops.pack_conv_weights(w, mode)
+        bias = torch.zeros(cout, device=dev)
+        stats_in = ops.gn_stats_zeros(batch, 8, dev)
+        stats_in.view(batch, 32, 8, 2)[:, 0, :, 1] = float(frames * s * s * cin // 8)     # unit variance statistics
+        stats_out = ops.gn_stats_zeros(batch, 8, dev)
+        gamma = torch.ones(cin, device=dev); beta = torch.zeros(cin, device=dev)
+        kwargs = dict(mode=mode, bias=bias)
+        if kind == 'c3':
+            kwargs.update(k=3, out_stats=stats_out)
+        elif kind == 'c3p':
+            kwargs.update(k=3, in_stats=stats_in, gamma=gamma, beta=beta, out_stats=stats_out)
+        elif kind == 'c1':
+            kwargs.update(k=1)
+        elif kind == 'down':
+            kwargs.update(k=4, stride=2)
+        else:
+            kwargs.update(k=4, kind=1)
+        ops.conv_forward(x, pw, cout, **kwargs)                                          # warm-up
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            ops.conv_forward(x, pw, cout, **kwargs)
+        e1.record(st)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        sym = f'conv_igemm_kernel<{mode},{64 if cout <= 64 else 128}>'
+        launches = 4 if kind == 'up' else 1                                              # the 4 phases are one launch (grid.z)
+        d = per_symbol.setdefault(sym, dict(ms=0.0, flops=0.0, launches=0))
+        d['ms'] += ms; d['flops'] += conv_flops(layer, frames, batch); d['launches'] += 1
+        del x, w, pw
+    return per_symbol
+
+
+def cpu_baseline(dim, frames, size, budget_s=20.0):
+    """CPU restatement (PyTorch-CPU, NOT JAX) of the same UNet forward at B=1, timed on this node's host cores."""
+    from oracle import unet3d_ref as R
+    cfg = R.UnetConfig(dim=dim, channels=1)
+    p = R.random_params(cfg, seed=0)
+    x = torch.randn(1, 1, frames, size, size)
+    t = torch.tensor([500])
+    cores = min(len(os.sched_getaffinity(0)), os.cpu_count() or 1, 16)     # the box's CPU share, not the host's core count
+    torch.set_num_threads(cores)
+    with torch.no_grad():
+        R.unet_forward(p, cfg, x, t)                                                     # warm-up
+        n, t0 = 0, time.time()
+        while n < 3 or (time.time() - t0 < budget_s and n < 10):
+            R.unet_forward(p, cfg, x, t); n += 1
+        dt = (time.time() - t0) / n
+    return dict(value=frames / (T_STEPS * dt), unit='frames/s', cores=cores, kind='port',
+                sample=f'{n} Unet3D forwards (B=1, fp32, oracle/unet3d_ref.py on torch-CPU, {dt*1e3:.0f} ms each) extrapolated x{T_STEPS} steps')
+
+
+def log(msg):
+    print(f'[bench +{time.time() - _T0:6.1f}s] {msg}', file=sys.stderr, flush=True)
+
+
+_T0 = time.time()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('VDX_BENCH_BATCH', 8)), help='videos per GPU')
+    ap.add_argument('--mode', default=os.environ.get('VDX_BENCH_MODE', 'bf16'), choices=['bf16', 'f32'])
+    ap.add_argument('--dim', type=int, default=64)
+    ap.add_argument('--frames', type=int, default=16)
+    ap.add_argument('--size', type=int, default=64)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP path has no CPU fallback)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from video_diffusion_nnx_amd import _lib as L
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion, vdx_p_sample_loop
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+
+    B, Fr, S = args.batch, args.frames, args.size
+    unet = Unet3D(dim=args.dim, rngs=0, channels=1, mode=args.mode, device=dev)
+    gd = GaussianDiffusion(unet, image_size=S, num_frames=Fr, channels=1, timesteps=T_STEPS, loss_type='l2')
+    h = unet.handle(Fr, S)
+    ws = unet.workspace(B, Fr, S)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        img = gd.randn((B, 1, Fr, S, S), 1000 + rank, 0)
+        eps = torch.empty(B, Fr, S, S, 1, device=dev)
+        t_dev = torch.full((B,), T_STEPS - 1, dtype=torch.int32, device=dev)
+        step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        packed = unet.packed()
+
+        def run(n):
+            L.check(vdx_p_sample_loop(h.ptr, L.ptr(unet.flat_params), L.ptr(packed), L.ptr(img), L.ptr(eps), L.ptr(t_dev), L.ptr(step_dev),
+                                      L.ptr(gd._ptab), T_STEPS, n, 0, 1000 + rank, 1, L.ptr(ws), ws.numel(), B, 1, L.stream_ptr()))
+        log(f'rank {rank}: model ready (B={B}, mode={args.mode}); warm-up ...')
+        run(max(args.warmup, 2))                       # untimed: eager step + graph capture + replays
+        torch.cuda.synchronize(dev)
+        log('warm-up done; timing ...')
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(args.steps)                                # timed: exactly K graph replays
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(img).all(), 'sampling produced non-finite values'
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * Fr / (T_STEPS * ms_per_step * 1e-3)
+
+    line = {
+        'metric': 'denoised frames/sec, 16fx64x64 1000-step DDPM', 'value': value, 'unit': 'frames/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.mode, 'data': 'synthetic',
+        'config': {'workload': f'config_v2_2 (north-star shape): Unet3D dim={args.dim} C=1, {Fr}f x {S}x{S}, DDPM T={T_STEPS} p_sample_loop '
+                               f'(UNet forward + p_sample per step, hipGraph replay); value = n_gpus*B*F/(T*s_per_step)',
+                   'batch_per_gpu': B, 'timesteps': T_STEPS, 'parallelism': f'dp{world} (independent samples, no collective)',
+                   'mfma_operands': args.mode, 'storage': 'fp32'},
+    }
+    log(f'timed region done: {ms_per_step:.3f} ms/step')
+    if rank == 0 and not args.no_roofline:
+        log('roofline leg: replaying conv_igemm launch shapes ...')
+        with torch.cuda.stream(stream):
+            per = time_conv_kernels(unet, Fr, S, B, args.mode)
+        sym, d = max(per.items(), key=lambda kv: kv[1]['ms'])
+        achieved = d['flops'] / d['launches'] / (d['ms'] / d['launches'] * 1e-3) / 1e12
+        peak = MFMA_PEAK_TFLOPS[args.mode]
+        line['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
+                            'kernel': sym, 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
+                            'avg_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
+                            'share_of_step': d['ms'] / ms_per_step,
+                            'all_conv_symbols': {k: {'ms_per_step': v['ms'], 'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} for k, v in per.items()}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log('cpu_baseline leg (oracle on host cores) ...')
+        line['cpu_baseline'] = cpu_baseline(args.dim, Fr, S)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -168,6 +168,45 @@ int vdx_unet_forward(const vdx_handle* h, const float* params, const void* packe
                      const float* cond, const unsigned char* cond_mask, int null_all, float* out, void* workspace,
                      size_t workspace_bytes, int batch, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * GaussianDiffusion device work.  External tensors [B,C,F,H,W]; eps_hat is the UNet output, channel-last.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* N(0,1) stream replacing jax.random.normal (gaussian_diffusion.py:254,309,416,445): Philox4x32-10 keyed by `seed`,
+ * draw number = offset (+ *dev_offset when given, a device counter advanced by the sampling loop). */
+int vdx_randn(float* out, long n, uint64_t seed, uint64_t offset, const uint64_t* dev_offset, void* stream);
+
+/* q_sample (gaussian_diffusion.py:401-420) with normalize_img folded in: x_t = sqrt_ac[t] (x0*pre_scale+pre_shift)
+ * + sqrt_1m_ac[t] noise.  t device int32 [B]; tables are device fp32 [T]. */
+int vdx_q_sample(const float* x_start, const int* t, const float* noise, float* out, const float* sqrt_ac,
+                 const float* sqrt_one_minus_ac, int batch, long per_sample, float pre_scale, float pre_shift, void* stream);
+
+/* p_sample (gaussian_diffusion.py:231-261 incl. predict_start_from_noise :120-136, clip :203-220, q_posterior :139-159).
+ * tables: device fp32 [5][T] = sqrt_recip_ac | sqrt_recipm1_ac | posterior_mean_coef1 | posterior_mean_coef2 |
+ * posterior_log_variance_clipped.  noise NULL -> Philox(seed, offset + *dev_offset) (per_sample % 4 == 0 required).
+ * thres: per-sample dynamic-threshold s [B] or NULL.  x and out may alias. */
+int vdx_p_sample_step(const float* x, const float* eps_hat, float* out, const int* t, const float* tables, int timesteps,
+                      const float* noise, uint64_t seed, uint64_t offset, const uint64_t* dev_offset, const float* thres,
+                      int clip_denoised, int batch, int channels, long per_sample, void* stream);
+
+/* sum |eps_hat - noise| (l2 == 0) or (eps_hat - noise)^2 (l2 != 0) accumulated into *acc (device double, pre-zeroed);
+ * the mean of gaussian_diffusion.py:463-466 is acc / (batch*channels*fhw). */
+int vdx_loss_sum(const float* eps_hat, const float* noise, double* acc, int batch, int channels, long fhw, int l2, void* stream);
+
+/* y = a x + b (normalize_img / unnormalize_img, utils.py:259-280). */
+int vdx_affine(const float* x, float* y, long n, float a, float b, void* stream);
+
+/* p_sample_loop (gaussian_diffusion.py:264-320): img holds x_T on entry and x_0 (still in [-1,1]) on return.
+ * t_dev [B] int32 must hold T-1, *step_dev (device uint64) must be 0 on entry; eps_buf [B,F,H,W,out_dim] scratch.
+ * One step = Unet3D forward + p_sample + (t -= 1); with use_graph != 0 the step is captured once into a hipGraph on
+ * `stream` (which must not be the legacy default stream) and replayed, so the loop issues no per-step host work.
+ * Draw k of the noise stream is Philox(seed, 1 + k); the caller draws x_T itself (e.g. vdx_randn with offset 0).
+ * nsteps (<= timesteps) steps are enqueued, continuing from the state in t_dev / step_dev, so a loop may be issued in
+ * pieces.  The instantiated graph is cached in the handle and reused while every argument but nsteps is unchanged. */
+int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
+                      uint64_t* step_dev, const float* tables, int timesteps, int nsteps, const float* cond, uint64_t seed,
+                      int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,152 @@
+"""GPU parity of the GaussianDiffusion kernels and the sampling loop vs oracle/diffusion_ref.py + philox_ref.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import philox_ref, unet3d_ref as R
+from oracle.diffusion_ref import DiffusionRef
+
+DEV = 'cuda:0'
+
+
+def _mk(T=10, loss='l1', mode='f32', kw=None, **gkw):
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    kw = kw or dict(dim=16, channels=3)
+    unet = Unet3D(rngs=0, mode=mode, **kw)
+    return GaussianDiffusion(unet, image_size=8, num_frames=2, channels=kw['channels'], timesteps=T, loss_type=loss, **gkw)
+
+
+@pytest.mark.parametrize('n', [0, 1, 5, 4096, 1000003])
+def test_randn_matches_philox_restatement(n):
+    gd = _mk()
+    z = gd.randn((n,), key=0x1234567890ABCDEF, offset=3).cpu().numpy()
+    ref = philox_ref.randn(n, 0x1234567890ABCDEF, 3)
+    assert z.shape == ref.shape
+    if n:
+        np.testing.assert_allclose(z, ref, atol=3e-6, rtol=1e-5)     # integer stream exact; libm ulps in log/sincos
+
+
+def test_q_sample_and_known_answers():
+    gd = _mk()
+    ref = DiffusionRef(None, image_size=8, num_frames=2, channels=3, timesteps=10)
+    g = torch.Generator().manual_seed(42)
+    x = torch.ones(2, 3, 2, 8, 8)
+    noise = torch.randn(x.shape, generator=g)
+    t = torch.tensor([0, 5])
+    np.testing.assert_allclose(gd.q_sample(x, t, noise=noise).cpu(), ref.q_sample(x, t, noise), atol=1e-6)
+    t0 = torch.zeros(2, dtype=torch.int64)                              # gaussian_diffusion_test.py:135-158
+    exp = ref.tab['sqrt_alphas_cumprod'][0] * x + ref.tab['sqrt_one_minus_alphas_cumprod'][0] * noise
+    np.testing.assert_allclose(gd.q_sample(x, t0, noise=noise).cpu(), exp, atol=1e-6)
+    # predict_start(q_sample(x, t, 0), t, 0) == x   (gaussian_diffusion_test.py:111-123)
+    tm = torch.full((2,), 5)
+    xt = gd.q_sample(x, tm, noise=torch.zeros_like(x))
+    np.testing.assert_allclose(gd.predict_start_from_noise(xt, tm.to(DEV), torch.zeros_like(xt)).cpu(), x, atol=1e-4)
+    assert gd.q_sample(x, t, key=3).shape == x.shape
+
+
+@pytest.mark.parametrize('clip', [True, False])
+def test_p_sample_step_elementwise(clip):
+    from video_diffusion_nnx_amd import _lib as L
+    from video_diffusion_nnx_amd.gaussian_diffusion import vdx_p_sample_step
+    gd = _mk(T=10)
+    ref = DiffusionRef(None, image_size=8, num_frames=2, channels=3, timesteps=10)
+    g = torch.Generator().manual_seed(5)
+    x = 2 * torch.randn(3, 3, 2, 8, 8, generator=g)
+    eps = torch.randn(3, 2, 8, 8, 3, generator=g)
+    z = torch.randn(x.shape, generator=g)
+    t = torch.tensor([0, 4, 9])
+    xd, ed, zd, td = x.to(DEV), eps.to(DEV), z.to(DEV), t.to(DEV, torch.int32)
+    out = torch.empty_like(xd)
+    L.check(vdx_p_sample_step(L.ptr(xd), L.ptr(ed), L.ptr(out), L.ptr(td), L.ptr(gd._ptab), 10, L.ptr(zd), 0, 0, 0, 0, int(clip), 3, 3,
+                              x.numel() // 3, L.stream_ptr()))
+    np.testing.assert_allclose(out.cpu(), ref.p_sample(x, t, z, clip_denoised=clip, eps_pred=eps), atol=2e-5)
+    # t = 0 returns the posterior mean (gaussian_diffusion_test.py:175-189)
+    mean0, _, _ = ref.p_mean_variance(x, t, clip, eps_pred=eps)
+    np.testing.assert_allclose(out.cpu()[0], mean0[0], atol=1e-5)
+    # Philox-generated noise == explicit noise taken from the restated stream
+    zp = torch.from_numpy(philox_ref.randn(x.numel(), 77, 6)).reshape(x.shape)
+    L.check(vdx_p_sample_step(L.ptr(xd), L.ptr(ed), L.ptr(out), L.ptr(td), L.ptr(gd._ptab), 10, 0, 77, 6, 0, 0, int(clip), 3, 3,
+                              x.numel() // 3, L.stream_ptr()))
+    np.testing.assert_allclose(out.cpu(), ref.p_sample(x, t, zp, clip_denoised=clip, eps_pred=eps), atol=3e-5)
+
+
+def test_loss_known_answers():                                         # gaussian_diffusion_test.py:191-210
+    from video_diffusion_nnx_amd import _lib as L
+    from video_diffusion_nnx_amd.gaussian_diffusion import vdx_loss_sum
+    B, C, fhw = 2, 3, 2 * 8 * 8
+    eps_hat = torch.zeros(B, 2, 8, 8, C, device=DEV)
+    for target, l2, expect in ((0.0, 0, 0.0), (0.5, 0, 0.5), (0.5, 1, 0.25)):
+        acc = torch.zeros(1, dtype=torch.float64, device=DEV)
+        noise = torch.full((B, C, 2, 8, 8), target, device=DEV)
+        L.check(vdx_loss_sum(L.ptr(eps_hat), L.ptr(noise), L.ptr(acc), B, C, fhw, l2, L.stream_ptr()))
+        assert abs(acc.item() / (B * C * fhw) - expect) < 1e-6
+    # channel-last <-> channel-first re-indexing with C = 3
+    g = torch.Generator().manual_seed(0)
+    e = torch.randn(B, 2, 8, 8, C, generator=g)
+    n = torch.randn(B, C, 2, 8, 8, generator=g)
+    acc = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ed, nd = e.to(DEV), n.to(DEV)          # keep the device tensors alive across the asynchronous launch
+    L.check(vdx_loss_sum(L.ptr(ed), L.ptr(nd), L.ptr(acc), B, C, fhw, 1, L.stream_ptr()))
+    assert abs(acc.item() / n.numel() - ((e.permute(0, 4, 1, 2, 3) - n) ** 2).mean().item()) < 1e-5
+
+
+@pytest.mark.parametrize('loss', ['l1', 'l2'])
+def test_p_losses_and_call_vs_oracle(loss):
+    kw = dict(dim=16, channels=3)
+    gd = _mk(T=50, loss=loss, kw=kw)
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=2, dtype=torch.float64)
+    gd.denoise_fn.load_state_dict({k: v.float() for k, v in p.items()})
+    ref = DiffusionRef(lambda x, t: R.unet_forward(p, cfg, x, t), image_size=8, num_frames=2, channels=3, timesteps=50,
+                       loss_type=loss, dtype=torch.float64)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(2, 3, 2, 8, 8, generator=g)
+    noise = torch.randn(x.shape, generator=g)
+    t = torch.tensor([3, 41])
+    got = gd.p_losses(x, t, noise=noise)
+    assert got.shape == ()
+    assert abs(got.item() - ref.p_losses(x.double(), t, noise.double()).item()) < 2e-5
+    assert gd(x, key=9).shape == ()                                     # scalar loss (gaussian_diffusion_test.py:212-218)
+
+
+def test_p_sample_loop_matches_oracle_loop():
+    """End to end: Philox x_T and per-step noise restated on the CPU, oracle UNet as denoiser; graph == eager."""
+    kw = dict(dim=16, channels=1)
+    T, B = 6, 2
+    gd = _mk(T=T, kw=kw)
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=3, dtype=torch.float64)
+    gd.denoise_fn.load_state_dict({k: v.float() for k, v in p.items()})
+    shape = (B, 1, 2, 8, 8)
+    seed = 2024
+    out_graph = gd.p_sample_loop(shape, seed, use_graph=True)
+    out_eager = gd.p_sample_loop(shape, seed, use_graph=False)
+    torch.cuda.synchronize()
+    assert out_graph.shape == shape                                      # gaussian_diffusion_test.py:224-230
+    # GroupNorm partial sums are accumulated with f64 atomics: order-dependent in the last bit, so not bitwise
+    np.testing.assert_allclose(out_graph.cpu(), out_eager.cpu(), atol=1e-5)
+    n = int(np.prod(shape))
+    ref = DiffusionRef(lambda x, t: R.unet_forward(p, cfg, x, t), image_size=8, num_frames=2, channels=1, timesteps=T, dtype=torch.float64)
+    xT = torch.from_numpy(philox_ref.randn(n, seed, 0)).double().reshape(shape)
+    noises = [torch.from_numpy(philox_ref.randn(n, seed, 1 + k)).double().reshape(shape) for k in range(T)]
+    exp = ref.p_sample_loop(xT, noises)
+    np.testing.assert_allclose(out_graph.cpu().double(), exp, atol=2e-4)
+    assert gd.sample(seed, batch_size=B).shape == shape                  # :232-246 (no cond)
+
+
+def test_dynamic_threshold_path():
+    kw = dict(dim=16, channels=1)
+    gd = _mk(T=4, kw=kw, use_dynamic_thres=True)
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=3, dtype=torch.float64)
+    gd.denoise_fn.load_state_dict({k: v.float() for k, v in p.items()})
+    g = torch.Generator().manual_seed(0)
+    x = 3 * torch.randn(2, 1, 2, 8, 8, generator=g)
+    z = torch.randn(x.shape, generator=g)
+    t = torch.tensor([2, 3])
+    ref = DiffusionRef(lambda a, b: R.unet_forward(p, cfg, a, b), image_size=8, num_frames=2, channels=1, timesteps=4,
+                       use_dynamic_thres=True, dtype=torch.float64)
+    np.testing.assert_allclose(gd.p_sample(x, t, key=None, noise=z).cpu().double(), ref.p_sample(x.double(), t, z.double()), atol=1e-4)

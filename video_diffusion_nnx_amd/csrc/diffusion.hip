@@ -1,0 +1,188 @@
+// GaussianDiffusion device work (gfx950): HBM-bound elementwise kernels + the sampling loop driver.
+//
+//   randn ............ counter-based N(0,1) stream (Philox4x32-10 + Box-Muller), replaces jax.random.normal
+//                      (gaussian_diffusion.py:254,309,416,445); restated for parity in oracle/philox_ref.py
+//   q_sample ......... sqrt(ac_t) x0 + sqrt(1-ac_t) eps                         gaussian_diffusion.py:401-420
+//   p_sample_step .... eps_hat -> x0_hat -> clip -> posterior mean -> + sigma z   gaussian_diffusion.py:120-159,162-261
+//   loss ............. mean |eps_hat - eps| or (eps_hat - eps)^2                 gaussian_diffusion.py:460-468
+//   p_sample_loop .... T x { Unet3D forward ; p_sample_step ; t -= 1 } on one stream, the step captured once
+//                      in a hipGraph and replayed (no host work per step)      gaussian_diffusion.py:264-320
+// External tensors are [B,C,F,H,W]; the UNet output eps_hat is channel-last [B,F,H,W,C] (unet3d.py:387) and is
+// re-indexed on the fly (the reference's rearrange at gaussian_diffusion.py:197,460).
+#include "vdx_common.h"
+#include "vdx_internal.h"
+#include "model.h"
+
+namespace vdx {
+
+struct Philox { unsigned c[4]; };
+
+__device__ __forceinline__ Philox philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned hi0 = (unsigned)(p0 >> 32), lo0 = (unsigned)p0, hi1 = (unsigned)(p1 >> 32), lo1 = (unsigned)p1;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Philox o; o.c[0] = c0; o.c[1] = c1; o.c[2] = c2; o.c[3] = c3;
+    return o;
+}
+
+// four normals of counter i of draw `offset` (see oracle/philox_ref.py for the exact definition)
+__device__ __forceinline__ float4 randn4(unsigned long long i, unsigned long long seed, unsigned long long offset) {
+    const Philox r = philox4x32_10((unsigned)i, (unsigned)(i >> 32), (unsigned)offset, (unsigned)(offset >> 32), (unsigned)seed, (unsigned)(seed >> 32));
+    float u[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) u[k] = ((float)(r.c[k] >> 8) + 0.5f) * 5.9604644775390625e-08f;   // 2^-24
+    float4 z;
+    const float r0 = sqrtf(-2.0f * logf(u[0])), r1 = sqrtf(-2.0f * logf(u[2]));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u[1], &s0, &c0);
+    sincosf(6.283185307179586f * u[3], &s1, &c1);
+    z.x = r0 * c0; z.y = r0 * s0; z.z = r1 * c1; z.w = r1 * s1;
+    return z;
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, long n, unsigned long long seed,
+                                                    unsigned long long offset, const unsigned long long* __restrict__ dev_offset) {
+    if (dev_offset) offset += *dev_offset;
+    const long nq = (n + 3) / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (long)gridDim.x * blockDim.x) {
+        const float4 z = randn4((unsigned long long)i, seed, offset);
+        if (4 * i + 3 < n) *reinterpret_cast<float4*>(out + 4 * i) = z;
+        else { const float v[4] = {z.x, z.y, z.z, z.w}; for (int k = 0; 4 * i + k < n; ++k) out[4 * i + k] = v[k]; }
+    }
+}
+
+// x_t = a[t_b] * (x0 * pre_scale + pre_shift) + b[t_b] * noise     (pre_* = normalize_img of __call__, :499)
+__global__ __launch_bounds__(256) void q_sample_kernel(const float* __restrict__ x0, const int* __restrict__ t,
+                                                       const float* __restrict__ noise, float* __restrict__ out,
+                                                       const float* __restrict__ sqrt_ac, const float* __restrict__ sqrt_1mac,
+                                                       long per_sample, float pre_scale, float pre_shift) {
+    const int b = blockIdx.y;
+    const float a = sqrt_ac[t[b]], s = sqrt_1mac[t[b]];
+    const size_t base = (size_t)b * per_sample;
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < per_sample; i += (long)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < per_sample) {
+            const float4 x = *reinterpret_cast<const float4*>(x0 + base + i);
+            const float4 n = *reinterpret_cast<const float4*>(noise + base + i);
+            float4 o;
+            o.x = a * fmaf(x.x, pre_scale, pre_shift) + s * n.x; o.y = a * fmaf(x.y, pre_scale, pre_shift) + s * n.y;
+            o.z = a * fmaf(x.z, pre_scale, pre_shift) + s * n.z; o.w = a * fmaf(x.w, pre_scale, pre_shift) + s * n.w;
+            *reinterpret_cast<float4*>(out + base + i) = o;
+        } else {
+            for (long k = i; k < per_sample; ++k) out[base + k] = a * fmaf(x0[base + k], pre_scale, pre_shift) + s * noise[base + k];
+        }
+    }
+}
+
+// one reverse step.  tables: [5][T] = sqrt_recip_ac | sqrt_recipm1_ac | post_mean_coef1 | post_mean_coef2 | post_logvar_clipped
+__global__ __launch_bounds__(256) void p_sample_kernel(PSampleArgs P) {
+    const int b = blockIdx.y;
+    const int tb = P.t[b];
+    const float k_recip = P.tables[tb], k_recipm1 = P.tables[P.T + tb];
+    const float c1 = P.tables[2 * P.T + tb], c2 = P.tables[3 * P.T + tb];
+    const float sigma = (tb == 0) ? 0.f : expf(0.5f * P.tables[4 * P.T + tb]);
+    const float s = P.thres ? P.thres[b] : 1.0f;
+    unsigned long long off = P.offset;
+    if (P.dev_offset) off += *P.dev_offset;
+    const long per = P.per_sample, fhw = P.per_sample / P.C;
+    const size_t base = (size_t)b * per;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; 4 * q < per; q += (long)gridDim.x * blockDim.x) {
+        const long i = 4 * q;
+        float xv[4], ev[4], nv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long e = i + k;
+            xv[k] = ev[k] = 0.f;
+            if (e < per) {
+                xv[k] = P.x[base + e];
+                const long c = e / fhw, r = e - c * fhw;                 // [C,F,H,W] -> channel-last [F,H,W,C]
+                ev[k] = P.eps[base + r * P.C + c];
+            }
+        }
+        if (P.noise) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nv[k] = (i + k < per) ? P.noise[base + i + k] : 0.f;
+        } else {
+            const float4 z = randn4((unsigned long long)(base / 4 + q), P.seed, off);   // element index of the whole tensor
+            nv[0] = z.x; nv[1] = z.y; nv[2] = z.z; nv[3] = z.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float x0 = k_recip * xv[k] - k_recipm1 * ev[k];                // predict_start_from_noise  (:133-136)
+            if (P.clip) x0 = fminf(fmaxf(x0, -s), s) / s;                  // :220
+            const float mean = c1 * x0 + c2 * xv[k];                       // q_posterior (:153-156)
+            const float o = mean + sigma * nv[k];                          // :261
+            if (i + k < per) P.out[base + i + k] = o * P.post_scale + P.post_shift;
+        }
+    }
+}
+
+__global__ void advance_kernel(int* t, int B, unsigned long long* dev_offset) {
+    const int i = threadIdx.x;
+    if (i < B && t[i] > 0) t[i] -= 1;
+    if (i == 0 && dev_offset) *dev_offset += 1;
+}
+
+// sum over all elements of |eps_hat - eps| or (eps_hat - eps)^2 -> acc[0] (double); host divides by the count
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ eps_hat, const float* __restrict__ noise, double* acc,
+                                                   int B, int Cc, long fhw, int l2) {
+    __shared__ float red[4];
+    const long n = (long)B * Cc * fhw;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / (Cc * fhw), r = i - b * Cc * fhw;
+        const long c = r / fhw, p = r - c * fhw;
+        const float d = eps_hat[(b * fhw + p) * Cc + c] - noise[i];
+        s += l2 ? d * d : fabsf(d);
+    }
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(acc, (double)(red[0] + red[1] + red[2] + red[3]));
+}
+
+__global__ void affine_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a, float b) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = fmaf(x[i], a, b);
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------------
+
+static int ew_blocks(long work_items) { return (int)std::max<long>(1, std::min<long>((work_items + 255) / 256, 2048)); }
+
+hipError_t launch_randn(float* out, long n, unsigned long long seed, unsigned long long offset, const unsigned long long* dev_offset, hipStream_t st) {
+    hipLaunchKernelGGL(randn_kernel, dim3(ew_blocks((n + 3) / 4)), dim3(256), 0, st, out, n, seed, offset, dev_offset);
+    return hipGetLastError();
+}
+
+hipError_t launch_q_sample(const float* x0, const int* t, const float* noise, float* out, const float* sqrt_ac, const float* sqrt_1mac,
+                           int B, long per_sample, float pre_scale, float pre_shift, hipStream_t st) {
+    hipLaunchKernelGGL(q_sample_kernel, dim3(ew_blocks((per_sample + 3) / 4), B), dim3(256), 0, st, x0, t, noise, out, sqrt_ac, sqrt_1mac,
+                       per_sample, pre_scale, pre_shift);
+    return hipGetLastError();
+}
+
+hipError_t launch_p_sample(const PSampleArgs& a, int B, hipStream_t st) {
+    hipLaunchKernelGGL(p_sample_kernel, dim3(ew_blocks((a.per_sample + 3) / 4), B), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_advance(int* t, int B, unsigned long long* dev_offset, hipStream_t st) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1024), 0, st, t, B, dev_offset);
+    return hipGetLastError();
+}
+
+hipError_t launch_loss(const float* eps_hat, const float* noise, double* acc, int B, int Cc, long fhw, int l2, hipStream_t st) {
+    hipLaunchKernelGGL(loss_kernel, dim3(ew_blocks((long)B * Cc * fhw)), dim3(256), 0, st, eps_hat, noise, acc, B, Cc, fhw, l2);
+    return hipGetLastError();
+}
+
+hipError_t launch_affine(const float* x, float* y, long n, float a, float b, hipStream_t st) {
+    hipLaunchKernelGGL(affine_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, x, y, n, a, b);
+    return hipGetLastError();
+}
+
+}  // namespace vdx

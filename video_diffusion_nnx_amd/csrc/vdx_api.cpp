@@ -5,7 +5,12 @@
 #include "vdx_internal.h"
 #include "model.h"
 
-struct vdx_handle { vdx::Model model; };
+struct vdx_handle {
+    vdx::Model model;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    struct GraphKey { const void* p[8]; unsigned long long seed; int i[4]; size_t ws; } graph_key;
+};
 
 static thread_local char g_err[512] = "";
 
@@ -170,6 +175,8 @@ int vdx_create(const vdx_config* cfg, vdx_handle** out) {
 
 void vdx_destroy(vdx_handle* h) {
     if (!h) return;
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
     if (h->model.d_ss_layers) (void)hipFree(h->model.d_ss_layers);
     delete h;
 }
@@ -214,6 +221,106 @@ int vdx_unet_forward(const vdx_handle* h, const float* params, const void* packe
     if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "unet_forward: handle was created without a GPU");
     return vdx::model_forward(&h->model, params, packed, x, time, cond, cond_mask, null_all, out, workspace, workspace_bytes, batch,
                               (hipStream_t)stream);
+}
+
+int vdx_randn(float* out, long n, uint64_t seed, uint64_t offset, const uint64_t* dev_offset, void* stream) {
+    if (n == 0) return VDX_OK;
+    if (!out || n < 0) VDX_FAIL(VDX_ERR_INVALID, "randn: bad argument");
+    VDX_HIP(vdx::launch_randn(out, n, seed, offset, reinterpret_cast<const unsigned long long*>(dev_offset), (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_q_sample(const float* x_start, const int* t, const float* noise, float* out, const float* sqrt_ac,
+                 const float* sqrt_one_minus_ac, int batch, long per_sample, float pre_scale, float pre_shift, void* stream) {
+    if (!x_start || !t || !noise || !out || !sqrt_ac || !sqrt_one_minus_ac || batch < 1 || per_sample < 1) VDX_FAIL(VDX_ERR_INVALID, "q_sample: bad argument");
+    if (per_sample % 4) VDX_FAIL(VDX_ERR_INVALID, "q_sample: per_sample must be a multiple of 4");
+    VDX_HIP(vdx::launch_q_sample(x_start, t, noise, out, sqrt_ac, sqrt_one_minus_ac, batch, per_sample, pre_scale, pre_shift, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+static int fill_psample(vdx::PSampleArgs& a, const float* x, const float* eps_hat, float* out, const int* t, const float* tables,
+                        int timesteps, const float* noise, uint64_t seed, uint64_t offset, const uint64_t* dev_offset,
+                        const float* thres, int clip, int channels, long per_sample) {
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.eps = eps_hat; a.out = out; a.t = t; a.tables = tables; a.T = timesteps; a.noise = noise;
+    a.seed = seed; a.offset = offset; a.dev_offset = reinterpret_cast<const unsigned long long*>(dev_offset);
+    a.thres = thres; a.clip = clip; a.C = channels; a.per_sample = per_sample; a.post_scale = 1.f; a.post_shift = 0.f;
+    return 0;
+}
+
+int vdx_p_sample_step(const float* x, const float* eps_hat, float* out, const int* t, const float* tables, int timesteps,
+                      const float* noise, uint64_t seed, uint64_t offset, const uint64_t* dev_offset, const float* thres,
+                      int clip_denoised, int batch, int channels, long per_sample, void* stream) {
+    if (!x || !eps_hat || !out || !t || !tables || timesteps < 1 || batch < 1 || channels < 1) VDX_FAIL(VDX_ERR_INVALID, "p_sample: bad argument");
+    if (per_sample % channels) VDX_FAIL(VDX_ERR_INVALID, "p_sample: per_sample must be a multiple of channels");
+    if (!noise && per_sample % 4) VDX_FAIL(VDX_ERR_INVALID, "p_sample: generated noise needs per_sample % 4 == 0");
+    vdx::PSampleArgs a;
+    fill_psample(a, x, eps_hat, out, t, tables, timesteps, noise, seed, offset, dev_offset, thres, clip_denoised, channels, per_sample);
+    VDX_HIP(vdx::launch_p_sample(a, batch, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_loss_sum(const float* eps_hat, const float* noise, double* acc, int batch, int channels, long fhw, int l2, void* stream) {
+    if (!eps_hat || !noise || !acc) VDX_FAIL(VDX_ERR_INVALID, "loss: null tensor");
+    VDX_HIP(vdx::launch_loss(eps_hat, noise, acc, batch, channels, fhw, l2, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_affine(const float* x, float* y, long n, float a, float b, void* stream) {
+    if (!x || !y || n < 0) VDX_FAIL(VDX_ERR_INVALID, "affine: bad argument");
+    if (n) VDX_HIP(vdx::launch_affine(x, y, n, a, b, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
+                      uint64_t* step_dev, const float* tables, int timesteps, int nsteps, const float* cond, uint64_t seed,
+                      int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream) {
+    if (!h || !params || !packed || !img || !eps_buf || !t_dev || !step_dev || !tables || !workspace) VDX_FAIL(VDX_ERR_INVALID, "p_sample_loop: null argument");
+    if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "p_sample_loop: handle was created without a GPU");
+    if (nsteps < 0 || nsteps > timesteps) VDX_FAIL(VDX_ERR_INVALID, "p_sample_loop: nsteps out of range");
+    const vdx::Model& m = h->model;
+    const long per_sample = (long)m.cfg.channels * m.cfg.num_frames * m.cfg.image_size * m.cfg.image_size;
+    if (per_sample % 4) VDX_FAIL(VDX_ERR_INVALID, "p_sample_loop: C*F*H*W must be a multiple of 4");
+    if (m.out_dim != m.cfg.channels) VDX_FAIL(VDX_ERR_INVALID, "p_sample_loop: out_dim must equal channels");
+    hipStream_t st = (hipStream_t)stream;
+    auto step = [&]() -> int {
+        // reference p_sample_loop never forwards cond (Q10); when a cond tensor is supplied it is used un-masked
+        int rc = vdx::model_forward(&m, params, packed, img, t_dev, cond, nullptr, 0, eps_buf, workspace, workspace_bytes, batch, st);
+        if (rc != VDX_OK) return rc;
+        vdx::PSampleArgs a;
+        fill_psample(a, img, eps_buf, img, t_dev, tables, timesteps, nullptr, seed, 1, step_dev, nullptr, clip_denoised, m.cfg.channels, per_sample);
+        hipError_t e = vdx::launch_p_sample(a, batch, st);
+        if (e == hipSuccess) e = vdx::launch_advance(t_dev, batch, reinterpret_cast<unsigned long long*>(step_dev), st);
+        if (e != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__);
+        return VDX_OK;
+    };
+    if (!use_graph) {
+        for (int i = 0; i < nsteps; ++i) { int rc = step(); if (rc != VDX_OK) return rc; }
+        return VDX_OK;
+    }
+    vdx_handle::GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.p[0] = params; key.p[1] = packed; key.p[2] = img; key.p[3] = eps_buf; key.p[4] = t_dev; key.p[5] = step_dev;
+    key.p[6] = tables; key.p[7] = cond; key.seed = seed; key.i[0] = timesteps; key.i[1] = clip_denoised; key.i[2] = batch;
+    key.i[3] = (int)(uintptr_t)workspace; key.ws = workspace_bytes ^ (size_t)(uintptr_t)stream;
+    int done = 0;
+    if (!h->graph_exec || memcmp(&key, &h->graph_key, sizeof(key)) != 0) {
+        if (nsteps == 0) return VDX_OK;
+        int rc = step();                                    // eager first step (also sets kernel attributes before capture)
+        if (rc != VDX_OK) return rc;
+        done = 1;
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+        VDX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = step();
+        hipError_t ce = hipStreamEndCapture(st, &h->graph);
+        if (rc != VDX_OK) return rc;
+        if (ce != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(ce), __FILE__, __LINE__);
+        VDX_HIP(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
+        h->graph_key = key;
+    }
+    for (int i = done; i < nsteps; ++i) VDX_HIP(hipGraphLaunch(h->graph_exec, st));
+    return VDX_OK;
 }
 
 }  // extern "C"

@@ -84,6 +84,23 @@ struct SlaArgs {
 size_t sla_workspace_bytes(int mode, int NF, int N, int heads);
 hipError_t launch_sla(int mode, SlaArgs a, hipStream_t st);
 
+struct PSampleArgs {
+    const float* x; const float* eps; float* out;       // x/out [B,C,F,H,W] (may alias); eps channel-last [B,F,H,W,C]
+    const int* t; const float* tables; int T;           // device t[B]; tables [5][T]
+    const float* noise;                                 // explicit z [B,C,F,H,W], or null -> Philox(seed, offset + *dev_offset)
+    unsigned long long seed, offset; const unsigned long long* dev_offset;
+    const float* thres;                                 // per-sample dynamic threshold s[B] or null (s = 1)
+    int clip; int C; long per_sample;
+    float post_scale, post_shift;
+};
+hipError_t launch_randn(float* out, long n, unsigned long long seed, unsigned long long offset, const unsigned long long* dev_offset, hipStream_t st);
+hipError_t launch_q_sample(const float* x0, const int* t, const float* noise, float* out, const float* sqrt_ac, const float* sqrt_1mac,
+                           int B, long per_sample, float pre_scale, float pre_shift, hipStream_t st);
+hipError_t launch_p_sample(const PSampleArgs& a, int B, hipStream_t st);
+hipError_t launch_advance(int* t, int B, unsigned long long* dev_offset, hipStream_t st);
+hipError_t launch_loss(const float* eps_hat, const float* noise, double* acc, int B, int Cc, long fhw, int l2, hipStream_t st);
+hipError_t launch_affine(const float* x, float* y, long n, float a, float b, hipStream_t st);
+
 size_t conv_packed_bytes(int mode, int taps, int Cin, int Cout);
 int conv_cin_pad(int mode, int Cin);
 hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, int Cin, int Cout, hipStream_t st);
