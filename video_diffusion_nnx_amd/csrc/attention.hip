@@ -64,28 +64,54 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs P) {
     const char* wo = reinterpret_cast<const char*>(P.wo);
     const int nkt = P.CPad / KT;
 
+    // x tile: resident across the 8 heads when C fits one K tile; else re-staged per head from L2
+    const bool x_resident = (nkt == 1);
+    auto stage_x = [&](int kt) {
+        for (int i = tid; i < 64 * APIECES; i += 256) {
+            const int row = i / APIECES, pc = i % APIECES;
+            const int c = kt * KT + pc * 4;
+            const long ro = rowoff[row];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ro >= 0 && c < P.C) v = *reinterpret_cast<const float4*>(P.x + ro + c);
+            M::store4(xs + row * RS, pc * 4, v);
+        }
+    };
+    // per-head weight tile (96 rows x 128 B) prefetched through registers one K tile ahead
+    uint4 wpre[3];
+    auto wfetch = [&](int h, int kt) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + 256 * j;
+            const int row = i >> 3, pc = i & 7;
+            const int grow = (row >> 5) * HD + h * D + (row & 31);
+            wpre[j] = *reinterpret_cast<const uint4*>(wq + ((size_t)grow * P.CPad + (size_t)kt * KT) * M::ES + pc * 16);
+        }
+    };
+    auto wput = [&]() {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int i = tid + 256 * j;
+            *reinterpret_cast<uint4*>(ws + (i >> 3) * RS + (i & 7) * 16) = wpre[j];
+        }
+    };
+    if (x_resident) stage_x(0);
+    wfetch(0, 0);
+
     for (int h = 0; h < P.heads; ++h) {
         // ---------------- GEMM1: q,k,v of head h for the 64 rows ----------------
         f32x4 acc[3][2];
 #pragma unroll
         for (int i = 0; i < 3; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         for (int kt = 0; kt < nkt; ++kt) {
+            __syncthreads();                              // previous readers of xs / ws are done
+            if (!x_resident) stage_x(kt);
+            wput();
             __syncthreads();
-            for (int i = tid; i < 64 * APIECES; i += 256) {
-                const int row = i / APIECES, pc = i % APIECES;
-                const int c = kt * KT + pc * 4;
-                const long ro = rowoff[row];
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ro >= 0 && c < P.C) v = *reinterpret_cast<const float4*>(P.x + ro + c);
-                M::store4(xs + row * RS, pc * 4, v);
+            {
+                int nh = h, nk = kt + 1;
+                if (nk == nkt) { nk = 0; nh = h + 1; }
+                if (nh < P.heads) wfetch(nh, nk);
             }
-            for (int i = tid; i < 96 * 8; i += 256) {
-                const int row = i >> 3, pc = i & 7;
-                const int grow = (row >> 5) * HD + h * D + (row & 31);
-                *reinterpret_cast<uint4*>(ws + row * RS + pc * 16) =
-                    *reinterpret_cast<const uint4*>(wq + ((size_t)grow * P.CPad + (size_t)kt * KT) * M::ES + pc * 16);
-            }
-            __syncthreads();
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 uint4 bf[2], af[3];
@@ -156,7 +182,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs P) {
 #pragma unroll
             for (int jt = 0; jt < QT; ++jt)
                 M::store4(ps + qrow * RSV, jt * 16 + 4 * q, make_float4(s[jt][0] * inv, s[jt][1] * inv, s[jt][2] * inv, s[jt][3] * inv));
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // P rows are private to this wave: LDS ops of one wave stay in order
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -20,7 +20,11 @@
 
 namespace vdx {
 
-template <int MODE, int BC>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0xFFFFFFF0u;      // buffer-load offset beyond num_records: the hardware returns zeros
+
+// TN = 16-pixel tiles per wave (4: 64 pixels, 2: 32 pixels).  Workgroup tile = BC channels x BM pixels.
+template <int MODE, int BC, int TN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
     using M = Mma<MODE>;
     constexpr int KT = M::KT;
@@ -28,7 +32,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
     constexpr int WAVES_C = BC / 64;
     constexpr int WAVES_P = 4 / WAVES_C;
     constexpr int TM = 4;
-    constexpr int TN = (128 / WAVES_P) / 16;
     constexpr int APIECES = KT / 4;                 // float4 pieces per staged pixel row
     constexpr int WREGS = BC * 8 / 256;             // 16-byte weight pieces per thread per tap
 
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
     const int lp = lane & 15, q = lane >> 4;
     const int wc = wave % WAVES_C, wpx = wave / WAVES_C;
 
-    // ---- block decode -------------------------------------------------------------------------
+    // ---- block decode (all wave-uniform) --------------------------------------------------------
     int bx = blockIdx.x;
     const int tx = bx % P.tiles_x; bx /= P.tiles_x;
     const int ty = bx % P.tiles_y;
@@ -61,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
     // ---- LDS carve (every offset a multiple of 16 bytes) ------------------------------------------
     size_t off = 0;
     float* chs = reinterpret_cast<float*>(smem + off); off += 2 * BC * 4;          // [2][BC] channel sum / sumsq
-    int* hp_src = reinterpret_cast<int*>(smem + off); off += ((HPX * 4 + 15) / 16) * 16;   // [HPX] global pixel or -1
+    int* hp_pix = reinterpret_cast<int*>(smem + off); off += ((HPX * 4 + 15) / 16) * 16;   // [HPX] global pixel or -1
     float* coefA = nullptr; float* coefD = nullptr; float* gmean = nullptr;
     if (P.pro) {
         coefA = reinterpret_cast<float*>(smem + off); off += (size_t)P.CinPad * 4;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
         const int r = hp - patch * (IH * IW);
         const int iy = r / IW, ix = r - iy * IW;
         const int gy = iy0 + iy, gx = ix0 + ix, f = f0 + patch;
-        hp_src[hp] = (f < P.NF && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W) ? ((f * P.H + gy) * P.W + gx) : -1;
+        hp_pix[hp] = (f < P.NF && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W) ? ((f * P.H + gy) * P.W + gx) : -1;
     }
     if (P.pro) {
         // per-channel affine of GroupNorm-apply (+ time scale/shift):  x_hat = x * a + d
@@ -104,9 +107,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
     }
     __syncthreads();
 
+    // ---- buffer descriptors: 32-bit offsets, out-of-range reads return 0 (no bounds branches) ------
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x0), 0, P.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x1 ? P.x1 : P.x0), 0, P.x1 ? P.x1_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(P.wp), 0, P.w_bytes, 0x00020000);
+
     // ---- per-lane activation-fragment offsets ----------------------------------------------------
     int pixoff[TN];
-    bool pvalid[TN];
     int gout[TN];                                    // output pixel index (into y, channel-last) or -1
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -116,9 +123,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
         const int py = r / P.PW, px = r - py * P.PW;
         pixoff[tn] = ((patch * IH + py * P.stride) * IW + px * P.stride) * RS + q * 16;
         const int oy = oy0 + py, ox = ox0 + px, f = f0 + patch;
-        pvalid[tn] = (f < P.NF) && (oy < P.Ho) && (ox < P.Wo);
+        const bool ok = (f < P.NF) && (oy < P.Ho) && (ox < P.Wo);
         const int yy = P.kind ? (2 * oy + ry) : oy, xx = P.kind ? (2 * ox + rx) : ox;
-        gout[tn] = pvalid[tn] ? ((f * P.Hy + yy) * P.Wy + xx) : -1;
+        gout[tn] = ok ? ((f * P.Hy + yy) * P.Wy + xx) : -1;
     }
 
     f32x4 acc[TM][TN];
@@ -127,66 +134,79 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- weight staging helpers ------------------------------------------------------------------
-    uint4 wreg[WREGS];
-    const char* wbase = reinterpret_cast<const char*>(P.wp);
-    auto wload = [&](int tap, int cc) {
-        int widx = tap;
-        if (P.kind) { const int dy = tap >> 1, dx = tap & 1; widx = (2 * dy + ry) * 4 + (2 * dx + rx); }
+    // ---- weight staging: per-thread constant row offsets, per-phase uniform offset -----------------
+    unsigned wvoff[WREGS];
+    int wdst[WREGS];
 #pragma unroll
-        for (int k = 0; k < WREGS; ++k) {
-            const int i = tid + 256 * k;
-            const int row = i >> 3, pc = i & 7;
-            const int co = c0 + row;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (co < P.Cout)
-                v = *reinterpret_cast<const uint4*>(wbase + (((size_t)widx * P.Cout + co) * P.CinPad + (size_t)cc * KT) * M::ES + pc * 16);
-            wreg[k] = v;
-        }
+    for (int k = 0; k < WREGS; ++k) {
+        const int row = (tid >> 3) + 32 * k;
+        const int co = min(c0 + row, P.Cout - 1);     // rows past Cout re-read the last row; their outputs are never stored
+        wvoff[k] = (unsigned)(co * P.CinPad) * M::ES + (tid & 7) * 16;
+        wdst[k] = row * RS + (tid & 7) * 16;
+    }
+    const unsigned tap_stride = (unsigned)(P.Cout * P.CinPad) * M::ES;
+    u32x4 wreg[WREGS];
+    auto wload = [&](int dy, int dx, int cc) {
+        const int widx = P.kind ? ((2 * dy + ry) * 4 + (2 * dx + rx)) : (dy * KW + dx);
+        const unsigned so = (unsigned)widx * tap_stride + (unsigned)(cc * KT) * M::ES;
+#pragma unroll
+        for (int k = 0; k < WREGS; ++k) wreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[k], so, 0);
     };
     auto wstore = [&](int buf) {
-        char* dst = Ws + (size_t)buf * BC * RS;
+        char* dst = Ws + buf * (BC * RS);
 #pragma unroll
-        for (int k = 0; k < WREGS; ++k) {
-            const int i = tid + 256 * k;
-            const int row = i >> 3, pc = i & 7;
-            *reinterpret_cast<uint4*>(dst + row * RS + pc * 16) = wreg[k];
-        }
+        for (int k = 0; k < WREGS; ++k) *reinterpret_cast<u32x4*>(dst + wdst[k]) = wreg[k];
     };
 
     // ---- main loop: K tiles of cin x taps --------------------------------------------------------
+    const int total = HPX * APIECES;
     int buf = 0;
-    wload(0, 0);
+    wload(0, 0, 0);
     for (int cc = 0; cc < nchunks; ++cc) {
         if (cc) __syncthreads();                     // every wave is done reading the previous halo tile
-        for (int i = tid; i < HPX * APIECES; i += 256) {
-            const int hp = i / APIECES, pc = i - hp * APIECES;
-            const int c = cc * KT + pc * 4;
-            const int src = hp_src[hp];
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src >= 0 && c < Cin) {
-                v = (c < P.C0) ? *reinterpret_cast<const float4*>(P.x0 + (size_t)src * P.C0 + c)
-                               : *reinterpret_cast<const float4*>(P.x1 + (size_t)src * P.C1 + (c - P.C0));
-                if (P.pro) {
-                    const float4 a = *reinterpret_cast<const float4*>(coefA + c);
-                    const float4 d = *reinterpret_cast<const float4*>(coefD + c);
-                    v.x = silu_f(fmaf(v.x, a.x, d.x)); v.y = silu_f(fmaf(v.y, a.y, d.y));
-                    v.z = silu_f(fmaf(v.z, a.z, d.z)); v.w = silu_f(fmaf(v.w, a.w, d.w));
+        for (int i0 = tid; i0 < total; i0 += 1024) {
+            u32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u;
+                const int hp = i / APIECES, pc = i % APIECES;
+                const int c = cc * KT + pc * 4;
+                const int pix = (i < total) ? hp_pix[hp] : -1;
+                const unsigned o0 = (pix >= 0 && c < P.C0) ? (unsigned)(pix * P.C0 + c) * 4u : OOB;
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0);
+                if (P.C1) {
+                    const unsigned o1 = (pix >= 0 && c >= P.C0 && c < Cin) ? (unsigned)(pix * P.C1 + (c - P.C0)) * 4u : OOB;
+                    v[u] |= __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
                 }
             }
-            M::store4(As + (size_t)hp * RS, pc * 4, v);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 256 * u;
+                if (i < total) {
+                    const int hp = i / APIECES, pc = i % APIECES;
+                    float4 f = make_float4(__uint_as_float(v[u].x), __uint_as_float(v[u].y), __uint_as_float(v[u].z), __uint_as_float(v[u].w));
+                    if (P.pro) {
+                        const int c = cc * KT + pc * 4;
+                        const bool ok = hp_pix[hp] >= 0 && c < Cin;       // zero padding stays zero AFTER the activation
+                        const float4 a = *reinterpret_cast<const float4*>(coefA + c);
+                        const float4 d = *reinterpret_cast<const float4*>(coefD + c);
+                        f.x = ok ? silu_f(fmaf(f.x, a.x, d.x)) : 0.f; f.y = ok ? silu_f(fmaf(f.y, a.y, d.y)) : 0.f;
+                        f.z = ok ? silu_f(fmaf(f.z, a.z, d.z)) : 0.f; f.w = ok ? silu_f(fmaf(f.w, a.w, d.w)) : 0.f;
+                    }
+                    M::store4(As + hp * RS, pc * 4, f);
+                }
+            }
         }
+        int dy = 0, dx = 0;
         for (int tap = 0; tap < ntaps; ++tap) {
             wstore(buf);
             __syncthreads();
-            {   // prefetch the next weight tile while this one is consumed
-                int ntap = tap + 1, ncc = cc;
-                if (ntap == ntaps) { ntap = 0; ncc = cc + 1; }
-                if (ncc < nchunks) wload(ntap, ncc);
-            }
-            const int dy = tap / KW, dx = tap - dy * KW;
+            int ndy = dy, ndx = dx + 1, ncc = cc;
+            if (ndx == KW) { ndx = 0; ndy = dy + 1; }
+            if (ndy == KH) { ndy = 0; ncc = cc + 1; }
+            if (ncc < nchunks) wload(ndy, ndx, ncc);      // prefetch the next weight tile while this one is consumed
             const int tapoff = (dy * IW + dx) * RS;
-            const char* wt = Ws + (size_t)buf * BC * RS + (wc * 64 + lp) * RS + q * 16;
+            const char* wt = Ws + buf * (BC * RS) + (wc * 64 + lp) * RS + q * 16;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 uint4 bf[TN], af[TM];
@@ -199,6 +219,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
             }
+            dy = ndy; dx = ndx;
             buf ^= 1;
         }
     }
@@ -269,14 +290,14 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, void* __restr
 
 // ---- host-side launchers ----------------------------------------------------------------------------
 
-static void choose_patch(int NF, int F, int Ho, int Wo, int stride, int K, int& PH, int& PW, int& NP) {
+static void choose_patch(int BM, int NF, int F, int Ho, int Wo, int stride, int K, int& PH, int& PW, int& NP) {
     int pw = 4;
     while (pw < Wo && pw < 16) pw *= 2;
     long best = -1;
-    PH = 128 / pw; PW = pw; NP = 1;
-    for (int np = 1; np <= 8; np *= 2) {
+    PH = BM / pw; PW = pw; NP = 1;
+    for (int np = 1; np <= 16; np *= 2) {
         if (F % np) continue;
-        const int ph = 128 / (pw * np);
+        const int ph = BM / (pw * np);
         if (ph < 1) continue;
         const int IH = (ph - 1) * stride + K, IW = (pw - 1) * stride + K;
         if ((long)np * IH * IW > 400) continue;                  // keep the halo tile within the LDS budget
@@ -312,26 +333,38 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     if (a.kind) { a.stride = 1; a.Ho = a.H; a.Wo = a.W; a.Hy = 2 * a.H; a.Wy = 2 * a.W; }
     else { a.Ho = (a.H + a.stride - 1) / a.stride; a.Wo = (a.W + a.stride - 1) / a.stride; a.Hy = a.Ho; a.Wy = a.Wo; }
     a.CinPad = conv_cin_pad(mode, a.C0 + a.C1);
-    choose_patch(a.NF, a.F, a.Ho, a.Wo, a.stride, K, a.PH, a.PW, a.NP);
+    const int ES = mode == MODE_F32 ? 4 : 2;
+    const size_t npix = (size_t)a.NF * a.H * a.W;
+    const size_t b0 = npix * a.C0 * 4, b1 = npix * a.C1 * 4, bw = (size_t)(a.kind ? 16 : a.kh * a.kw) * a.Cout * a.CinPad * ES;
+    if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
+    a.x0_bytes = (unsigned)b0; a.x1_bytes = (unsigned)b1; a.w_bytes = (unsigned)bw;
+    // variant: 64-channel tiles take 256 pixels per workgroup (stride 1) so every wave owns a 64x64 tile
+    const int BC = a.Cout <= 64 ? 64 : 128;
+    const int TN = (BC == 64 && a.stride == 2) ? 2 : 4;
+    const int BM = 16 * TN * (4 / (BC / 64));
+    choose_patch(BM, a.NF, a.F, a.Ho, a.Wo, a.stride, K, a.PH, a.PW, a.NP);
     a.tiles_y = (a.Ho + a.PH - 1) / a.PH;
     a.tiles_x = (a.Wo + a.PW - 1) / a.PW;
-    const int BC = a.Cout <= 64 ? 64 : 128;
     const int IH = (a.PH - 1) * a.stride + K, IW = (a.PW - 1) * a.stride + K;
     const int HPX = a.NP * IH * IW;
     size_t lds = 2 * BC * 4 + ((HPX * 4 + 15) / 16) * 16 + (a.pro ? (2 * a.CinPad * 4 + 64 * 4) : 0)
                + (size_t)HPX * ROW_STRIDE + 2 * (size_t)BC * ROW_STRIDE;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((a.NF / a.NP) * a.tiles_y * a.tiles_x, (a.Cout + BC - 1) / BC, a.kind ? 4 : 1);
-#define VDX_LAUNCH_CONV(MODE_, BC_)                                                                      \
+#define VDX_LAUNCH_CONV(MODE_, BC_, TN_)                                                                 \
     do {                                                                                                  \
-        auto kfn = conv_igemm_kernel<MODE_, BC_>;                                                         \
+        auto kfn = conv_igemm_kernel<MODE_, BC_, TN_>;                                                    \
         if (lds > 64 * 1024) {                                                                            \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                \
         }                                                                                                 \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);                                             \
     } while (0)
-    if (mode == MODE_F32) { if (BC == 64) VDX_LAUNCH_CONV(MODE_F32, 64); else VDX_LAUNCH_CONV(MODE_F32, 128); }
-    else { if (BC == 64) VDX_LAUNCH_CONV(MODE_BF16, 64); else VDX_LAUNCH_CONV(MODE_BF16, 128); }
+    if (mode == MODE_F32) {
+        if (BC == 128) VDX_LAUNCH_CONV(MODE_F32, 128, 4); else if (TN == 4) VDX_LAUNCH_CONV(MODE_F32, 64, 4); else VDX_LAUNCH_CONV(MODE_F32, 64, 2);
+    } else {
+        if (BC == 128) VDX_LAUNCH_CONV(MODE_BF16, 128, 4); else if (TN == 4) VDX_LAUNCH_CONV(MODE_BF16, 64, 4); else VDX_LAUNCH_CONV(MODE_BF16, 64, 2);
+    }
 #undef VDX_LAUNCH_CONV
     return hipGetLastError();
 }

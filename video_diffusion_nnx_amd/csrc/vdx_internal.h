@@ -29,6 +29,7 @@ struct ConvArgs {
     double* out_stats; int out_groups;
     // completed by launch_conv
     int Ho, Wo, Hy, Wy, CinPad, PH, PW, NP, tiles_y, tiles_x;
+    unsigned x0_bytes, x1_bytes, w_bytes;          // buffer-descriptor extents
 };
 
 // out = SiLU(GroupNorm(y2; stats, gn_gamma, gn_beta)) + LayerNorm_C(r; ln_gamma, ln_beta), channel-last [B][pix][C]
