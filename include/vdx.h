@@ -207,6 +207,19 @@ int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, fl
                       uint64_t* step_dev, const float* tables, int timesteps, int nsteps, const float* cond, uint64_t seed,
                       int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Train step (reference trainer.py:322-392).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* d(mean loss)/d(eps_hat) for the l1 / l2 loss of gaussian_diffusion.py:463-466, written channel-last like eps_hat. */
+int vdx_loss_grad(const float* eps_hat, const float* noise, float* d_eps_hat, int batch, int channels, long fhw, int l2, void* stream);
+
+/* optax.adam + EMA on flat fp32 buffers (trainer.py:367-382): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= lr * (m / (1-b1^t)) / (sqrt(v / (1-b2^t)) + eps), t = step_count + 1; g is read as grad * grad_scale
+ * (1/world_size after a sum all-reduce).  If do_ema: ema = decay * ema + (1 - decay) * p_new. */
+int vdx_adam_ema_step(float* params, const float* grads, float* m, float* v, float* ema, long n, float lr, float b1, float b2,
+                      float eps, long step_count, float grad_scale, int do_ema, float ema_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

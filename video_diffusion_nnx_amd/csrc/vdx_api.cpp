@@ -323,4 +323,17 @@ int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, fl
     return VDX_OK;
 }
 
+int vdx_loss_grad(const float* eps_hat, const float* noise, float* d_eps_hat, int batch, int channels, long fhw, int l2, void* stream) {
+    if (!eps_hat || !noise || !d_eps_hat || batch < 1 || channels < 1 || fhw < 1) VDX_FAIL(VDX_ERR_INVALID, "loss_grad: bad argument");
+    VDX_HIP(vdx::launch_loss_grad(eps_hat, noise, d_eps_hat, batch, channels, fhw, l2, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_adam_ema_step(float* params, const float* grads, float* m, float* v, float* ema, long n, float lr, float b1, float b2,
+                      float eps, long step_count, float grad_scale, int do_ema, float ema_decay, void* stream) {
+    if (!params || !grads || !m || !v || (do_ema && !ema) || n < 1 || step_count < 0) VDX_FAIL(VDX_ERR_INVALID, "adam_ema_step: bad argument");
+    VDX_HIP(vdx::launch_adam_ema(params, grads, m, v, ema, n, lr, b1, b2, eps, step_count, grad_scale, do_ema, ema_decay, (hipStream_t)stream));
+    return VDX_OK;
+}
+
 }  // extern "C"

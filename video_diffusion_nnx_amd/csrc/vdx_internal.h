@@ -102,6 +102,10 @@ hipError_t launch_advance(int* t, int B, unsigned long long* dev_offset, hipStre
 hipError_t launch_loss(const float* eps_hat, const float* noise, double* acc, int B, int Cc, long fhw, int l2, hipStream_t st);
 hipError_t launch_affine(const float* x, float* y, long n, float a, float b, hipStream_t st);
 
+hipError_t launch_loss_grad(const float* eps_hat, const float* noise, float* d_eps, int B, int Cc, long fhw, int l2, hipStream_t st);
+hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float b1, float b2, float eps,
+                           long step_count, float grad_scale, int do_ema, float decay, hipStream_t st);
+
 size_t conv_packed_bytes(int mode, int taps, int Cin, int Cout);
 int conv_cin_pad(int mode, int Cin);
 hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, int Cin, int Cout, hipStream_t st);
