@@ -208,6 +208,31 @@ int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, fl
                       int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Backward building blocks (autodiff of the forward operators; reference trainer.py:361 jax.value_and_grad).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Transposed, tap-reversed packing [taps][Cin][CoutPad]: vdx_conv_forward(dy, this packing, cout = Cin) is the data
+ * gradient of a stride-1 conv; with kind swapped (Conv 4x4/s2 <-> ConvTranspose) it is the data gradient of
+ * Downsample / Upsample.  Size: vdx_packed_conv_bytes(mode, taps, cout, cin). */
+int vdx_pack_conv_weights_t(int mode, const float* kernel, void* packed, int taps, int cin, int cout, void* stream);
+
+typedef struct {
+    const float* x0; const float* x1; int c0, c1;      /* the conv's input (concat on channels) */
+    const float* dy; int cout;                         /* gradient of the conv's output [B*F, Ho, Wo, cout] */
+    float* dw;                                         /* Flax layout [taps][c0+c1][cout] fp32, ACCUMULATED (atomics) */
+    int batch, frames, h, w;                           /* input geometry */
+    int kind, kh, kw, stride;                          /* as vdx_conv_desc */
+    const double* in_stats; const float* gamma; const float* beta; int groups;     /* optional fused prologue of the forward */
+    const float* scale_shift; int scale_shift_stride;
+} vdx_wgrad_desc;
+
+/* dW += Xhat^T (*) dY on exact-f32 MFMA (both arithmetic modes use it). */
+int vdx_conv_backward_weights(const vdx_wgrad_desc* d, void* stream);
+
+/* out[c] += sum_rows x[row][c]  (bias gradients). */
+int vdx_colsum(const float* x, float* out, long rows, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Train step (reference trainer.py:322-392).
  * ---------------------------------------------------------------------------------------------- */
 

@@ -1,0 +1,97 @@
+"""GPU parity of the conv backward building blocks vs torch autograd through oracle/unet3d_ref.py."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import unet3d_ref as R
+
+DEV = 'cuda:0'
+
+
+def _rel(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+CASES = [
+    # B, F, H, W, Cin, Cout, k, stride, kind
+    (1, 4, 16, 16, 16, 32, 3, 1, 0),
+    (2, 2, 8, 8, 64, 64, 3, 1, 0),
+    (1, 3, 6, 10, 8, 24, 3, 1, 0),
+    (1, 2, 4, 4, 128, 64, 3, 1, 0),
+    (1, 4, 16, 16, 32, 32, 4, 2, 0),      # Downsample
+    (1, 4, 8, 8, 32, 32, 4, 1, 1),        # Upsample
+    (1, 2, 2, 2, 64, 64, 4, 1, 1),
+    (1, 4, 8, 8, 48, 40, 1, 1, 0),        # pointwise
+]
+
+
+def _fwd(x, kern, bias, k, stride, kind):
+    if kind == 1:
+        return R.conv_transpose_144(x, kern, bias)
+    if k == 1:
+        return R.conv_pointwise(x, kern[0], bias)
+    return R.conv_1kk(x, kern, bias, stride=stride)
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+@pytest.mark.parametrize('case', CASES)
+def test_conv_dgrad_wgrad_bias(mode, case):
+    from video_diffusion_nnx_amd import ops
+    B, Fr, H, W, Cin, Cout, k, stride, kind = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Fr, H, W, Cin, generator=g, dtype=torch.float64, requires_grad=True)
+    kern = (torch.randn(1, k, k, Cin, Cout, generator=g, dtype=torch.float64) / (k * k * Cin) ** 0.5).requires_grad_(True)
+    bias = torch.randn(Cout, generator=g, dtype=torch.float64, requires_grad=True)
+    y = _fwd(x, kern, bias, k, stride, kind)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    gx, gk, gb = torch.autograd.grad(y, (x, kern, bias), dy)
+    dyd = dy.float().to(DEV)
+    # data gradient = forward kernel with the transposed/flipped packing (and Down <-> Up swapped)
+    pwt = ops.pack_conv_weights_t(kern.detach().float().to(DEV), mode)
+    if kind == 1:
+        dx = ops.conv_forward(dyd, pwt, Cin, mode=mode, k=4, stride=2)
+    elif stride == 2:
+        dx = ops.conv_forward(dyd, pwt, Cin, mode=mode, kind=1)
+    else:
+        dx = ops.conv_forward(dyd, pwt, Cin, mode=mode, k=k)
+    tol = 2e-6 if mode == 'f32' else 8e-3
+    assert dx.shape == gx.shape
+    assert _rel(dx.cpu().double(), gx) < tol, (mode, case, _rel(dx.cpu().double(), gx))
+    dw = ops.conv_backward_weights(x.detach().float().to(DEV), dyd, kern.shape, kind=kind, k=k, stride=stride)
+    assert _rel(dw.cpu().double(), gk) < 5e-6, (case, _rel(dw.cpu().double(), gk))      # exact-f32 MFMA in both modes
+    db = ops.colsum(dyd)
+    assert _rel(db.cpu().double(), gb) < 5e-6
+
+
+def test_wgrad_concat_and_prologue():
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, Fr, H, W, C0, C1, Cout = 2, 2, 8, 8, 32, 16, 32
+    xa = torch.randn(B, Fr, H, W, C0, generator=g, dtype=torch.float64)
+    xb = torch.randn(B, Fr, H, W, C1, generator=g, dtype=torch.float64)
+    kern = (torch.randn(1, 3, 3, C0 + C1, Cout, generator=g, dtype=torch.float64) / 20).requires_grad_(True)
+    y = R.conv_1kk(torch.cat((xa, xb), -1), kern, None)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    (gk,) = torch.autograd.grad(y, kern, dy)
+    dw = ops.conv_backward_weights(xa.float().to(DEV), dy.float().to(DEV), kern.shape, x1=xb.float().to(DEV))
+    assert _rel(dw.cpu().double(), gk) < 5e-6
+    # prologue: Xhat = SiLU(GN(y1) * (s+1) + sh) recomputed inside the wgrad kernel
+    y1 = torch.randn(B, Fr, H, W, Cout, generator=g, dtype=torch.float64)
+    gamma, beta = 1 + 0.1 * torch.randn(Cout, generator=g, dtype=torch.float64), 0.1 * torch.randn(Cout, generator=g, dtype=torch.float64)
+    ss = 0.3 * torch.randn(B, 2 * Cout, generator=g, dtype=torch.float64)
+    k2 = (torch.randn(1, 3, 3, Cout, Cout, generator=g, dtype=torch.float64) / 17).requires_grad_(True)
+    h = R.group_norm(y1, gamma, beta, 8) * (ss[:, None, None, None, :Cout] + 1) + ss[:, None, None, None, Cout:]
+    y2 = R.conv_1kk(R.silu(h), k2, None)
+    dy2 = torch.randn(y2.shape, generator=g, dtype=torch.float64)
+    (gk2,) = torch.autograd.grad(y2, k2, dy2)
+    yg = y1.reshape(B, -1, 8, Cout // 8)
+    stats = torch.zeros(B, 32, 8, 2, dtype=torch.float64)
+    stats[:, 0, :, 0] = yg.sum(dim=(1, 3)); stats[:, 0, :, 1] = (yg * yg).sum(dim=(1, 3))
+    dw2 = ops.conv_backward_weights(y1.float().to(DEV), dy2.float().to(DEV), k2.shape, in_stats=stats.reshape(-1).to(DEV),
+                                    gamma=gamma.float().to(DEV), beta=beta.float().to(DEV), scale_shift=ss.float().to(DEV))
+    assert _rel(dw2.cpu().double(), gk2) < 2e-5

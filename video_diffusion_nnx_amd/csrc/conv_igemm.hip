@@ -141,10 +141,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
     for (int k = 0; k < WREGS; ++k) {
         const int row = (tid >> 3) + 32 * k;
         const int co = min(c0 + row, P.Cout - 1);     // rows past Cout re-read the last row; their outputs are never stored
-        wvoff[k] = (unsigned)(co * P.CinPad) * M::ES + (tid & 7) * 16;
+        wvoff[k] = (unsigned)((co + P.wrow0) * P.CinPad) * M::ES + (tid & 7) * 16;
         wdst[k] = row * RS + (tid & 7) * 16;
     }
-    const unsigned tap_stride = (unsigned)(P.Cout * P.CinPad) * M::ES;
+    const unsigned tap_stride = (unsigned)(P.wrows * P.CinPad) * M::ES;
     u32x4 wreg[WREGS];
     auto wload = [&](int dy, int dx, int cc) {
         const int widx = P.kind ? ((2 * dy + ry) * 4 + (2 * dx + rx)) : (dy * KW + dx);
@@ -238,6 +238,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
             v.x = acc[tm][tn][0] + bias.x; v.y = acc[tm][tn][1] + bias.y;
             v.z = acc[tm][tn][2] + bias.z; v.w = acc[tm][tn][3] + bias.w;
             if (cvalid && gout[tn] >= 0) {
+                if (P.res) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(P.res + (size_t)gout[tn] * P.Cout + co);
+                    v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
+                }
                 *reinterpret_cast<float4*>(P.y + (size_t)gout[tn] * P.Cout + co) = v;
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
@@ -288,6 +292,23 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, void* __restr
     }
 }
 
+// Transposed + tap-reversed packing for the data gradient: Flax kernel [taps][Cin][Cout] fp32 ->
+// [taps][Cin (rows)][CoutPad (K)], tap t' = taps-1-t.  conv(dy, this) == d/dx of conv(x, kernel) for stride 1,
+// and it turns Downsample's dgrad into the ConvTranspose kernel and vice versa (backward).
+template <int MODE>
+__global__ void pack_weights_t_kernel(const float* __restrict__ src, void* __restrict__ dst, int taps, int Cin, int Cout, int CoutPad) {
+    const size_t n = (size_t)taps * Cin * CoutPad;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % CoutPad);
+        const size_t r = i / CoutPad;
+        const int ci = (int)(r % Cin);
+        const int t = (int)(r / Cin);
+        const float v = (co < Cout) ? src[((size_t)(taps - 1 - t) * Cin + ci) * Cout + co] : 0.f;
+        if (MODE == MODE_F32) reinterpret_cast<float*>(dst)[i] = v;
+        else reinterpret_cast<__bf16*>(dst)[i] = (__bf16)v;
+    }
+}
+
 // ---- host-side launchers ----------------------------------------------------------------------------
 
 static void choose_patch(int BM, int NF, int F, int Ho, int Wo, int stride, int K, int& PH, int& PW, int& NP) {
@@ -327,6 +348,15 @@ hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, 
     return hipGetLastError();
 }
 
+hipError_t launch_pack_weights_t(int mode, const float* src, void* dst, int taps, int Cin, int Cout, hipStream_t st) {
+    const int CoutPad = conv_cin_pad(mode, Cout);
+    const size_t n = (size_t)taps * Cin * CoutPad;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
+    if (mode == MODE_F32) hipLaunchKernelGGL(pack_weights_t_kernel<MODE_F32>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CoutPad);
+    else hipLaunchKernelGGL(pack_weights_t_kernel<MODE_BF16>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CoutPad);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     // geometry completion
     const int K = a.kind ? 2 : a.kh;
@@ -335,7 +365,8 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     a.CinPad = conv_cin_pad(mode, a.C0 + a.C1);
     const int ES = mode == MODE_F32 ? 4 : 2;
     const size_t npix = (size_t)a.NF * a.H * a.W;
-    const size_t b0 = npix * a.C0 * 4, b1 = npix * a.C1 * 4, bw = (size_t)(a.kind ? 16 : a.kh * a.kw) * a.Cout * a.CinPad * ES;
+    if (a.wrows <= 0) { a.wrows = a.Cout; a.wrow0 = 0; }
+    const size_t b0 = npix * a.C0 * 4, b1 = npix * a.C1 * 4, bw = (size_t)(a.kind ? 16 : a.kh * a.kw) * a.wrows * a.CinPad * ES;
     if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
     a.x0_bytes = (unsigned)b0; a.x1_bytes = (unsigned)b1; a.w_bytes = (unsigned)bw;
     // variant: 64-channel tiles take 256 pixels per workgroup (stride 1) so every wave owns a 64x64 tile

@@ -323,6 +323,36 @@ int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, fl
     return VDX_OK;
 }
 
+int vdx_pack_conv_weights_t(int mode, const float* kernel, void* packed, int taps, int cin, int cout, void* stream) {
+    if (!kernel || !packed || taps <= 0 || cin <= 0 || cout <= 0) VDX_FAIL(VDX_ERR_INVALID, "pack_conv_weights_t: bad argument");
+    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
+    VDX_HIP(vdx::launch_pack_weights_t(mode, kernel, packed, taps, cin, cout, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_conv_backward_weights(const vdx_wgrad_desc* d, void* stream) {
+    if (!d || !d->x0 || !d->dy || !d->dw) VDX_FAIL(VDX_ERR_INVALID, "wgrad: null tensor");
+    if (d->c0 % 4 || d->c1 % 4 || d->cout % 4 || (d->c1 && !d->x1)) VDX_FAIL(VDX_ERR_INVALID, "wgrad: bad channels");
+    vdx::WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x0 = d->x0; a.x1 = d->x1; a.C0 = d->c0; a.C1 = d->c1; a.dy = d->dy; a.Cout = d->cout; a.dW = d->dw;
+    a.NF = d->batch * d->frames; a.F = d->frames; a.H = d->h; a.W = d->w;
+    a.kind = d->kind; a.kh = d->kind ? 4 : d->kh; a.kw = d->kind ? 4 : d->kw; a.stride = d->kind ? 1 : d->stride;
+    if (d->kind == 0 && (d->kh != d->kw || d->kh < 1 || d->kh > 4 || (d->stride != 1 && d->stride != 2))) VDX_FAIL(VDX_ERR_INVALID, "wgrad: unsupported kernel/stride");
+    if (d->in_stats) {
+        if (d->c1 || !d->gamma || !d->beta || d->groups <= 0 || d->groups > 32) VDX_FAIL(VDX_ERR_INVALID, "wgrad: bad prologue");
+        a.pro = 1; a.in_stats = d->in_stats; a.gamma = d->gamma; a.beta = d->beta; a.groups = d->groups; a.ss = d->scale_shift; a.ss_stride = d->scale_shift_stride;
+    }
+    VDX_HIP(vdx::launch_conv_wgrad(a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_colsum(const float* x, float* out, long rows, int c, void* stream) {
+    if (!x || !out || rows < 0 || c < 1 || c % 4) VDX_FAIL(VDX_ERR_INVALID, "colsum: bad argument");
+    if (rows) VDX_HIP(vdx::launch_colsum(x, out, rows, c, (hipStream_t)stream));
+    return VDX_OK;
+}
+
 int vdx_loss_grad(const float* eps_hat, const float* noise, float* d_eps_hat, int batch, int channels, long fhw, int l2, void* stream) {
     if (!eps_hat || !noise || !d_eps_hat || batch < 1 || channels < 1 || fhw < 1) VDX_FAIL(VDX_ERR_INVALID, "loss_grad: bad argument");
     VDX_HIP(vdx::launch_loss_grad(eps_hat, noise, d_eps_hat, batch, channels, fhw, l2, (hipStream_t)stream));

@@ -27,6 +27,8 @@ struct ConvArgs {
     const float* ss; int ss_stride; // per-sample [scale(Cin) | shift(Cin)] rows, or null
     // epilogue: GroupNorm partial statistics of the output (or null)
     double* out_stats; int out_groups;
+    const float* res;               // optional residual added to the output: y = conv + bias + res  ([.., Cout] like y)
+    int wrows, wrow0;               // packed weight rows per tap / first row (0,0 = Cout rows from 0): slices a wider packing
     // completed by launch_conv
     int Ho, Wo, Hy, Wy, CinPad, PH, PW, NP, tiles_y, tiles_x;
     unsigned x0_bytes, x1_bytes, w_bytes;          // buffer-descriptor extents
@@ -106,9 +108,25 @@ hipError_t launch_loss_grad(const float* eps_hat, const float* noise, float* d_e
 hipError_t launch_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long n, float lr, float b1, float b2, float eps,
                            long step_count, float grad_scale, int do_ema, float decay, hipStream_t st);
 
+// Weight gradient of a conv (kind 0: (kh,kw)/stride SAME; kind 1: ConvTranspose 4x4/2): dW += Xhat^T (*) dY
+struct WgradArgs {
+    const float* x0; const float* x1; int C0, C1;          // conv input (channel-last), optional concat
+    const float* dy; int Cout;                             // output gradient [NF, Hy, Wy, Cout]
+    float* dW;                                             // Flax layout [taps][Cin][Cout], accumulated with atomics
+    int NF, F, H, W;                                       // input geometry
+    int kind, kh, kw, stride;
+    int pro; const double* in_stats; const float* gamma; const float* beta; int groups; const float* ss; int ss_stride;
+    // completed by the launcher
+    int taps, sa, sb, ext, halo, Hm, Wm, Hy, Wy, PH, PW, co_tiles;
+};
+hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st);
+hipError_t launch_colsum(const float* x, float* out, long rows, int C, hipStream_t st);
+hipError_t launch_add_inplace(float* y, const float* x, long n, hipStream_t st);
+
 size_t conv_packed_bytes(int mode, int taps, int Cin, int Cout);
 int conv_cin_pad(int mode, int Cin);
 hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, int Cin, int Cout, hipStream_t st);
 hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st);
+hipError_t launch_pack_weights_t(int mode, const float* src, void* dst, int taps, int Cin, int Cout, hipStream_t st);
 
 }  // namespace vdx

@@ -1,0 +1,238 @@
+// Weight gradients of the (1,kh,kw) convolutions and 1x1 projections on exact-f32 MFMA (gfx950), and column sums.
+//
+//   dW[tap][ci][co] = sum_{pixels p} Xhat[p (+) tap][ci] * dY[p][co]        (autodiff of nnx.Conv / nnx.ConvTranspose,
+//                                                                            reference trainer.py:361 jax.value_and_grad)
+// Xhat is the conv's EFFECTIVE input: the channel-concat of two tensors and/or the fused prologue
+// SiLU(GroupNorm(x)*(scale+1)+shift) of conv_igemm -- recomputed here while staging, never stored.
+// GEMM view: M = ci, N = co, K = pixels.  Activations are channel-last, i.e. K-strided, which bf16 MFMA operands
+// cannot read without a transpose; v_mfma_f32_16x16x4_f32 takes ONE f32 per lane per operand (A[r][k=q], B[k=q][r]),
+// so the natural [pixel][channel] LDS image serves both operands with ds_read_b32.  All taps accumulate at once from a
+// single staged halo tile (<= 9 accumulator sets of 2x2 tiles per wave).  Split-K over pixel chunks; results are
+// added to the fp32 gradient buffer with float atomics (dW is tiny next to the activations).
+#include "vdx_common.h"
+#include "vdx_internal.h"
+
+namespace vdx {
+
+constexpr int WG_LD = 80;          // floats per LDS pixel row (64 channels + pad: q*80 % 32 = q*16 -> conflict-free halves)
+
+template <int NT>                   // taps handled by one workgroup (<= 9)
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wi = w & 1, wo = w >> 1;                       // 32-channel sub-tiles of the 64x64 (ci, co) tile
+    const int ci0 = blockIdx.y * 64, co0 = (blockIdx.z % P.co_tiles) * 64;
+    const int tap0 = (blockIdx.z / P.co_tiles) * NT;
+    const int Cin = P.C0 + P.C1;
+    const int IH = (P.PH - 1) * P.sa + P.ext, IW = (P.PW - 1) * P.sa + P.ext;     // staged input window
+    const int BH = P.PH * P.sb, BW = P.PW * P.sb;                                 // staged dY window
+    const int HPX = IH * IW, BPX = BH * BW;
+
+    float* As = reinterpret_cast<float*>(smem);              // [HPX][WG_LD]
+    float* Bs = As + (size_t)HPX * WG_LD;                    // [BPX][WG_LD]
+    float* coefA = Bs + (size_t)BPX * WG_LD;                 // [64] (prologue)
+    float* coefD = coefA + 64;
+    float* gm = coefD + 64;                                  // [64]
+    int* tapA = reinterpret_cast<int*>(gm + 64);             // [NT] LDS offsets (floats) of the tap shift in As / Bs
+    int* tapB = tapA + 16;
+
+    if (tid < NT) {
+        const int t = tap0 + tid;
+        int ay, ax, by = 0, bx = 0;
+        if (P.kind == 0) { ay = t / P.kw; ax = t % P.kw; }
+        else { const int jy = t >> 2, jx = t & 3; ay = (jy >> 1) + (jy & 1); ax = (jx >> 1) + (jx & 1); by = jy & 1; bx = jx & 1; }
+        tapA[tid] = (ay * IW + ax) * WG_LD;
+        tapB[tid] = (by * BW + bx) * WG_LD;
+    }
+
+    f32x4 acc[NT][2][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc[t][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int tiles_x = (P.Wm + P.PW - 1) / P.PW, tiles_y = (P.Hm + P.PH - 1) / P.PH;
+    const int patches_per_frame = tiles_x * tiles_y;
+    const long total_patches = (long)P.NF * patches_per_frame;
+    int last_b = -1;
+    for (long pid = blockIdx.x; pid < total_patches; pid += gridDim.x) {
+        const int f = (int)(pid / patches_per_frame);
+        const int pr = (int)(pid % patches_per_frame);
+        const int ty = pr / tiles_x, tx = pr % tiles_x;
+        const int my0 = ty * P.PH, mx0 = tx * P.PW;           // patch origin in "m" coordinates (conv: output pixels)
+        const int iy0 = my0 * P.sa - P.halo, ix0 = mx0 * P.sa - P.halo;
+        const int b = f / P.F;
+        __syncthreads();                                      // previous patch fully consumed
+        if (P.pro && b != last_b) {                           // per-sample prologue coefficients for this channel tile
+            if (tid < P.groups) {
+                float m, rs;
+                gn_mean_rstd(P.in_stats, b, tid, P.groups, (double)P.F * P.H * P.W * (Cin / P.groups), m, rs);
+                gm[2 * tid] = m; gm[2 * tid + 1] = rs;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int c = ci0 + tid;
+                float a = 0.f, d = 0.f;
+                if (c < Cin) {
+                    const int g = c / (Cin / P.groups);
+                    const float ga = P.gamma[c], be = P.beta[c];
+                    float sc = 1.f, sh = 0.f;
+                    if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + c] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + Cin + c]; }
+                    a = gm[2 * g + 1] * ga * sc;
+                    d = (be - gm[2 * g] * gm[2 * g + 1] * ga) * sc + sh;
+                }
+                coefA[tid] = a; coefD[tid] = d;
+            }
+            last_b = b;
+            __syncthreads();
+        }
+        // ---- stage the input window (64 channels) and the dY window (64 channels) ----
+        for (int i = tid; i < HPX * 16; i += 256) {
+            const int hp = i >> 4, pc = i & 15;
+            const int iy = hp / IW, ix = hp - iy * IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            const int c = ci0 + pc * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin) {
+                const size_t pix = ((size_t)f * P.H + gy) * P.W + gx;
+                v = (c < P.C0) ? *reinterpret_cast<const float4*>(P.x0 + pix * P.C0 + c)
+                               : *reinterpret_cast<const float4*>(P.x1 + pix * P.C1 + (c - P.C0));
+                if (P.pro) {
+                    const float4 a = *reinterpret_cast<const float4*>(coefA + pc * 4);
+                    const float4 d = *reinterpret_cast<const float4*>(coefD + pc * 4);
+                    v.x = silu_f(fmaf(v.x, a.x, d.x)); v.y = silu_f(fmaf(v.y, a.y, d.y));
+                    v.z = silu_f(fmaf(v.z, a.z, d.z)); v.w = silu_f(fmaf(v.w, a.w, d.w));
+                }
+            }
+            *reinterpret_cast<float4*>(As + (size_t)hp * WG_LD + pc * 4) = v;
+        }
+        for (int i = tid; i < BPX * 16; i += 256) {
+            const int bp = i >> 4, pc = i & 15;
+            const int yy = bp / BW, xx = bp - yy * BW;
+            const int gy = my0 * P.sb + yy, gx = mx0 * P.sb + xx;
+            const int c = co0 + pc * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < P.Hy && gx < P.Wy && c < P.Cout) v = *reinterpret_cast<const float4*>(P.dy + (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c);
+            *reinterpret_cast<float4*>(Bs + (size_t)bp * WG_LD + pc * 4) = v;
+        }
+        __syncthreads();
+        // ---- K loop over the patch's "m" positions, 4 per MFMA step (positions beyond Hm/Wm hold zero dY) ----
+        const int npos = P.PH * P.PW;
+        for (int k0 = 0; k0 < npos; k0 += 4) {
+            const int p = k0 + q;
+            const int py = p / P.PW, px = p - py * P.PW;
+            const float* arow = As + (size_t)((py * P.sa) * IW + px * P.sa) * WG_LD + wi * 32 + r;
+            const float* brow = Bs + (size_t)((py * P.sb) * BW + px * P.sb) * WG_LD + wo * 32 + r;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float a0 = arow[tapA[t]], a1 = arow[tapA[t] + 16];
+                const float b0 = brow[tapB[t]], b1 = brow[tapB[t] + 16];
+                acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[t][0][0], 0, 0, 0);
+                acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[t][0][1], 0, 0, 0);
+                acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[t][1][0], 0, 0, 0);
+                acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[t][1][1], 0, 0, 0);
+            }
+        }
+    }
+    // ---- accumulate into dW (Flax layout [taps][Cin][Cout]) ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = tap0 + t;
+        if (tap >= P.taps) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = co0 + wo * 32 + j * 16 + r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = ci0 + wi * 32 + i * 16 + 4 * q + e;
+                    if (ci < Cin && co < P.Cout) atomicAdd(P.dW + ((size_t)tap * Cin + ci) * P.Cout + co, acc[t][i][j][e]);
+                }
+            }
+    }
+}
+
+// out[c] += sum over rows of x[row][c]   (bias / LayerNorm-beta gradients); x is [rows][C] fp32
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int C) {
+    __shared__ float red[256];
+    const int cpt = (C + 3) / 4;                              // float4 columns
+    const int lanes_c = cpt < 256 ? cpt : 256;
+    const int rl = 256 / lanes_c;                             // row lanes per workgroup
+    const int cq = threadIdx.x % lanes_c, rq = threadIdx.x / lanes_c;
+    for (int cb = cq; cb < cpt; cb += lanes_c) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rq < rl)
+            for (long row = (long)blockIdx.x * rl + rq; row < rows; row += (long)gridDim.x * rl) {
+                const float4 v = *reinterpret_cast<const float4*>(x + row * C + cb * 4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        const float vals[4] = {s.x, s.y, s.z, s.w};
+        for (int e = 0; e < 4; ++e) {
+            __syncthreads();
+            red[threadIdx.x] = (rq < rl) ? vals[e] : 0.f;
+            __syncthreads();
+            if (rq == 0) {
+                float t = 0.f;
+                for (int k = 0; k < rl; ++k) t += red[k * lanes_c + cq];
+                if (cb * 4 + e < C) atomicAdd(out + cb * 4 + e, t);
+            }
+        }
+    }
+}
+
+// y[i] += x[i]
+__global__ void add_inplace_kernel(float* __restrict__ y, const float* __restrict__ x, long n) {
+    for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+        if (i + 3 < n) {
+            float4 a = *reinterpret_cast<float4*>(y + i);
+            const float4 b = *reinterpret_cast<const float4*>(x + i);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            *reinterpret_cast<float4*>(y + i) = a;
+        } else for (long k = i; k < n; ++k) y[k] += x[k];
+    }
+}
+
+hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
+    const int Cin = a.C0 + a.C1;
+    a.taps = a.kind ? 16 : a.kh * a.kw;
+    if (a.kind == 0) {
+        a.sa = a.stride; a.sb = 1; a.ext = a.kh; a.halo = (a.stride == 1) ? (a.kh - 1) / 2 : (a.kh - 2) / 2;
+        a.Hm = (a.H + a.stride - 1) / a.stride; a.Wm = (a.W + a.stride - 1) / a.stride; a.Hy = a.Hm; a.Wy = a.Wm;
+        if (a.stride == 1) { a.PH = 8; a.PW = 8; } else { a.PH = 4; a.PW = 8; }
+    } else {
+        a.sa = 1; a.sb = 2; a.ext = 3; a.halo = 1; a.Hm = a.H; a.Wm = a.W; a.Hy = 2 * a.H; a.Wy = 2 * a.W; a.PH = 4; a.PW = 8;
+    }
+    const int NT = a.taps <= 9 ? (a.taps == 1 ? 1 : 9) : 8;
+    const int tap_groups = (a.taps + NT - 1) / NT;
+    a.co_tiles = (a.Cout + 63) / 64;
+    const int ci_tiles = (Cin + 63) / 64;
+    const int IH = (a.PH - 1) * a.sa + a.ext, IW = (a.PW - 1) * a.sa + a.ext;
+    const size_t lds = ((size_t)IH * IW + (size_t)a.PH * a.sb * a.PW * a.sb) * WG_LD * 4 + 3 * 64 * 4 + 32 * 4;
+    const long patches = (long)a.NF * ((a.Hm + a.PH - 1) / a.PH) * ((a.Wm + a.PW - 1) / a.PW);
+    const long tiles = (long)ci_tiles * a.co_tiles * tap_groups;
+    long chunks = std::max<long>(1, std::min<long>(patches, 1024 / std::max<long>(1, tiles)));
+    dim3 grid((unsigned)chunks, ci_tiles, a.co_tiles * tap_groups);
+#define VDX_WG(NT_) do { auto kfn = conv_wgrad_kernel<NT_>;                                                           \
+        if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a); } while (0)
+    if (NT == 1) VDX_WG(1); else if (NT == 9) VDX_WG(9); else VDX_WG(8);
+#undef VDX_WG
+    return hipGetLastError();
+}
+
+hipError_t launch_colsum(const float* x, float* out, long rows, int C, hipStream_t st) {
+    const int cpt = (C + 3) / 4, lanes_c = cpt < 256 ? cpt : 256, rl = 256 / lanes_c;
+    const int blocks = (int)std::max<long>(1, std::min<long>((rows + rl - 1) / rl, 1024));
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, st, x, out, rows, C);
+    return hipGetLastError();
+}
+
+hipError_t launch_add_inplace(float* y, const float* x, long n, hipStream_t st) {
+    const int blocks = (int)std::max<long>(1, std::min<long>((n / 4 + 255) / 256, 2048));
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, st, y, x, n);
+    return hipGetLastError();
+}
+
+}  // namespace vdx

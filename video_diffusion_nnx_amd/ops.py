@@ -123,3 +123,54 @@ def sla_forward(x, wq, wk, wv, wo, heads, mode):
     L.check(L.vdx_sla_forward(m, L.ptr(x), L.ptr(y), L.ptr(pk[0]), L.ptr(pk[1]), L.ptr(pk[2]), L.ptr(pk[3]), L.ptr(ws),
                               B, Fr, H, W, C_, heads, L.stream_ptr()))
     return y
+
+
+# ---- backward building blocks ---------------------------------------------------------------------------
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('x0', C.c_void_p), ('x1', C.c_void_p), ('c0', C.c_int), ('c1', C.c_int), ('dy', C.c_void_p), ('cout', C.c_int),
+                ('dw', C.c_void_p), ('batch', C.c_int), ('frames', C.c_int), ('h', C.c_int), ('w', C.c_int),
+                ('kind', C.c_int), ('kh', C.c_int), ('kw', C.c_int), ('stride', C.c_int),
+                ('in_stats', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('groups', C.c_int),
+                ('scale_shift', C.c_void_p), ('scale_shift_stride', C.c_int)]
+
+
+_pack_t = L._sig('vdx_pack_conv_weights_t', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p])
+_wgrad = L._sig('vdx_conv_backward_weights', C.c_int, [C.POINTER(WgradDesc), C.c_void_p])
+_colsum = L._sig('vdx_colsum', C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_int, C.c_void_p])
+
+
+def pack_conv_weights_t(kernel: torch.Tensor, mode) -> torch.Tensor:
+    m = _mode(mode)
+    cin, cout = kernel.shape[-2], kernel.shape[-1]
+    taps = kernel.numel() // (cin * cout)
+    k = kernel.contiguous().float()
+    out = torch.empty(L.vdx_packed_conv_bytes(m, taps, cout, cin), dtype=torch.uint8, device=k.device)
+    L.check(_pack_t(m, L.ptr(k), L.ptr(out), taps, cin, cout, L.stream_ptr()))
+    return out
+
+
+def conv_backward_weights(x0, dy, kshape, *, x1=None, kind=0, k=3, stride=1, in_stats=None, gamma=None, beta=None, groups=8,
+                          scale_shift=None, dw=None) -> torch.Tensor:
+    B, Fr, H, W, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[-1]
+    cout = dy.shape[-1]
+    if dw is None:
+        dw = torch.zeros(kshape, dtype=torch.float32, device=x0.device)
+    d = WgradDesc()
+    d.x0, d.x1, d.c0, d.c1, d.dy, d.cout, d.dw = L.ptr(x0), L.ptr(x1), c0, c1, L.ptr(dy), cout, L.ptr(dw)
+    d.batch, d.frames, d.h, d.w = B, Fr, H, W
+    d.kind, d.kh, d.kw, d.stride = kind, k, k, stride
+    d.in_stats, d.gamma, d.beta, d.groups = L.ptr(in_stats), L.ptr(gamma), L.ptr(beta), groups
+    d.scale_shift = L.ptr(scale_shift)
+    d.scale_shift_stride = 0 if scale_shift is None else scale_shift.shape[-1]
+    L.check(_wgrad(C.byref(d), L.stream_ptr()))
+    return dw
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    c = x.shape[-1]
+    out = torch.zeros(c, dtype=torch.float32, device=x.device)
+    L.check(_colsum(L.ptr(x), L.ptr(out), x.numel() // c, c, L.stream_ptr()))
+    return out
