@@ -95,3 +95,43 @@ def test_wgrad_concat_and_prologue():
     dw2 = ops.conv_backward_weights(y1.float().to(DEV), dy2.float().to(DEV), k2.shape, in_stats=stats.reshape(-1).to(DEV),
                                     gamma=gamma.float().to(DEV), beta=beta.float().to(DEV), scale_shift=ss.float().to(DEV))
     assert _rel(dw2.cpu().double(), gk2) < 2e-5
+
+
+@pytest.mark.parametrize('C,B,shape,use_ss,tail', [(16, 2, (3, 5, 5), True, False), (64, 2, (4, 8, 8), True, False), (64, 1, (2, 8, 8), False, True),
+                                                   (256, 2, (2, 4, 4), False, True), (512, 1, (2, 2, 2), True, False), (1024, 1, (2, 2, 2), False, True),
+                                                   (24, 1, (2, 3, 3), False, True)])
+def test_norm_act_backward(C, B, shape, use_ss, tail):
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(C + B)
+    D = torch.float64
+    y = (torch.randn(B, *shape, C, generator=g, dtype=D) * 1.5 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g, dtype=D)).requires_grad_(True)
+    beta = (0.2 * torch.randn(C, generator=g, dtype=D)).requires_grad_(True)
+    ss = (0.3 * torch.randn(B, 2 * C, generator=g, dtype=D)).requires_grad_(True) if use_ss else None
+    r = torch.randn(B, *shape, C, generator=g, dtype=D).requires_grad_(True) if tail else None
+    lg = (1 + 0.2 * torch.randn(C, generator=g, dtype=D)).requires_grad_(True) if tail else None
+    lb = (0.1 * torch.randn(C, generator=g, dtype=D)).requires_grad_(True) if tail else None
+    h = R.group_norm(y, gamma, beta, 8)
+    if use_ss:
+        h = h * (ss[:, None, None, None, :C] + 1) + ss[:, None, None, None, C:]
+    out = R.silu(h)
+    if tail:
+        out = out + R.layer_norm(r, lg, lb)
+    dout = torch.randn(out.shape, generator=g, dtype=D)
+    wrt = [y, gamma, beta] + ([ss] if use_ss else []) + ([r, lg, lb] if tail else [])
+    grads = torch.autograd.grad(out, wrt, dout)
+    gy, ggam, gbet = grads[:3]
+    yg = y.detach().reshape(B, -1, 8, C // 8)
+    stats = torch.zeros(B, 32, 8, 2, dtype=D)
+    stats[:, 0, :, 0] = yg.sum(dim=(1, 3)); stats[:, 0, :, 1] = (yg * yg).sum(dim=(1, 3))
+    f = lambda t: None if t is None else t.detach().float().to(DEV)
+    res = ops.norm_act_backward(f(dout), f(y), stats.reshape(-1).to(DEV), f(gamma), f(beta), 8, scale_shift=f(ss), r=f(r), ln_gamma=f(lg))
+    assert _rel(res['dy'].cpu().double(), gy) < 3e-5, _rel(res['dy'].cpu().double(), gy)
+    assert _rel(res['d_gamma'].cpu().double(), ggam) < 3e-5 and _rel(res['d_beta'].cpu().double(), gbet) < 3e-5
+    i = 3
+    if use_ss:
+        assert _rel(res['dss'].cpu().double(), grads[i]) < 3e-5
+        i += 1
+    if tail:
+        assert _rel(res['dr'].cpu().double(), grads[i]) < 3e-5
+        assert _rel(res['d_ln_gamma'].cpu().double(), grads[i + 1]) < 3e-5 and _rel(res['d_ln_beta'].cpu().double(), grads[i + 2]) < 3e-5

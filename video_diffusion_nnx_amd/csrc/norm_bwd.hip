@@ -1,0 +1,258 @@
+// Backward of the fused normalisation/activation stages of ResnetBlock (gfx950), HBM-bound, float4-vectorised.
+//
+// Forward stage (reference modules.py:171-179, 233-243):   xh = (y - mu_g) * rstd_g ;  u = gamma * xh + beta ;
+//     z = u * (1 + s_bc) + sh_bc ;  act = SiLU(z)          [s, sh = 0 for Block 2 / no time MLP]
+// and, in the block tail, out = act + LayerNorm_C(r).
+// Given dact (= dL/dact, or dL/dout for the tail):
+//   reduce    R0[b,c] = sum_pix dz ,  R1[b,c] = sum_pix dz * xh   (dz = dact * SiLU'(z)); LN: dgamma_ln, dbeta_ln
+//   finalize  dgamma, dbeta, (ds, dsh), per-group S1 = sum_c k R0 / n, S2 = sum_c k R1 / n   with k = (1+s) gamma
+//   apply     dy = rstd_g * (k * dz - S1 - xh * S2) ;  LN: dr = rstd_p * (g*dout - mean_c(g*dout) - rh * mean_c(g*dout*rh))
+// (jax.value_and_grad of the same expressions, reference trainer.py:361.)
+#include "vdx_common.h"
+#include "vdx_internal.h"
+
+namespace vdx {
+
+__device__ __forceinline__ float dsilu_f(float z) {
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+    return sg * (1.0f + z * (1.0f - sg));
+}
+
+// shared by reduce and apply: per-channel tables for sample b in LDS
+struct NbTables { float* mu; float* rs; float* a; float* d; };
+
+__device__ __forceinline__ void nb_build_tables(const NormBwdArgs& P, int b, float* gm, NbTables T) {
+    const int tid = threadIdx.x, C = P.C;
+    if (tid < P.groups) {
+        float m, rs;
+        gn_mean_rstd(P.stats, b, tid, P.groups, (double)P.pix_per_sample * (C / P.groups), m, rs);
+        gm[2 * tid] = m; gm[2 * tid + 1] = rs;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / (C / P.groups);
+        const float m = gm[2 * g], rs = gm[2 * g + 1];
+        float sc = 1.f, sh = 0.f;
+        if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + c] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + C + c]; }
+        const float a = rs * P.gamma[c] * sc;
+        T.mu[c] = m; T.rs[c] = rs; T.a[c] = a; T.d[c] = (P.beta[c] - m * rs * P.gamma[c]) * sc + sh;
+    }
+    __syncthreads();
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs P) {
+    __shared__ float mu[1024], rsd[1024], ta[1024], td[1024];
+    __shared__ float gm[64];
+    __shared__ float red[256 * 4];
+    const int tid = threadIdx.x, C = P.C, b = blockIdx.y;
+    NbTables T{mu, rsd, ta, td};
+    nb_build_tables(P, b, gm, T);
+    const int LPP = P.lpp, ppb = 256 / LPP, sub = tid % LPP, pl = tid / LPP;
+    const float invC = 1.0f / (float)C;
+    float4 r0[VPL], r1[VPL], g0[VPL], g1[VPL];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) { r0[v] = r1[v] = g0[v] = g1[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    for (long pix = (long)blockIdx.x * ppb + pl; pix < P.pix_per_sample; pix += (long)gridDim.x * ppb) {
+        const size_t base = ((size_t)b * P.pix_per_sample + pix) * C;
+        float4 rr[VPL];
+        float mean = 0.f, rstd = 0.f;
+        if (P.r) {                                               // LayerNorm statistics of this pixel
+            float s = 0.f, ss = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const int c = (v * LPP + sub) * 4;
+                rr[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < C) {
+                    rr[v] = *reinterpret_cast<const float4*>(P.r + base + c);
+                    s += rr[v].x + rr[v].y + rr[v].z + rr[v].w;
+                    ss += rr[v].x * rr[v].x + rr[v].y * rr[v].y + rr[v].z * rr[v].z + rr[v].w * rr[v].w;
+                }
+            }
+            for (int o = 1; o < LPP; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+            mean = s * invC;
+            rstd = rsqrtf(fmaxf(ss * invC - mean * mean, 0.f) + NORM_EPS);
+        }
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c = (v * LPP + sub) * 4;
+            if (c < C) {
+                const float4 y = *reinterpret_cast<const float4*>(P.y + base + c);
+                const float4 da = *reinterpret_cast<const float4*>(P.dact + base + c);
+                const float yv[4] = {y.x, y.y, y.z, y.w}, dv[4] = {da.x, da.y, da.z, da.w};
+                float* p0 = &r0[v].x; float* p1 = &r1[v].x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z = fmaf(yv[e], ta[c + e], td[c + e]);
+                    const float dz = dv[e] * dsilu_f(z);
+                    p0[e] += dz;
+                    p1[e] += dz * (yv[e] - mu[c + e]) * rsd[c + e];
+                }
+                if (P.r) {
+                    const float rv[4] = {rr[v].x, rr[v].y, rr[v].z, rr[v].w};
+                    float* q0 = &g0[v].x; float* q1 = &g1[v].x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { q0[e] += dv[e] * (rv[e] - mean) * rstd; q1[e] += dv[e]; }
+                }
+            }
+        }
+    }
+    // ---- reduce over the workgroup's pixel lanes, then one atomic per (channel, quantity) ----
+    auto flush = [&](const float4& val, int c, float* dst0, int stride) {
+        __syncthreads();
+        *reinterpret_cast<float4*>(red + tid * 4) = val;
+        __syncthreads();
+        if (pl == 0 && c < C) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < ppb; ++k) {
+                const float4 u = *reinterpret_cast<const float4*>(red + (k * LPP + sub) * 4);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            atomicAdd(dst0 + (size_t)(c + 0) * stride, t.x); atomicAdd(dst0 + (size_t)(c + 1) * stride, t.y);
+            atomicAdd(dst0 + (size_t)(c + 2) * stride, t.z); atomicAdd(dst0 + (size_t)(c + 3) * stride, t.w);
+        }
+    };
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+        const int c = (v * LPP + sub) * 4;
+        flush(r0[v], c, P.R + (size_t)b * C * 2, 2);
+        flush(r1[v], c, P.R + (size_t)b * C * 2 + 1, 2);
+        if (P.r) { flush(g0[v], c, P.d_ln_gamma, 1); flush(g1[v], c, P.d_ln_beta, 1); }
+    }
+}
+
+// grid = batch.  Turns R into parameter gradients, (ds, dsh) and the per-group correction terms G[b][g][2].
+__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(NormBwdArgs P) {
+    __shared__ float s1[32], s2[32];
+    const int tid = threadIdx.x, C = P.C, b = blockIdx.x;
+    const int cpg = C / P.groups;
+    if (tid < 32) { s1[tid] = 0.f; s2[tid] = 0.f; }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const float R0 = P.R[((size_t)b * C + c) * 2], R1 = P.R[((size_t)b * C + c) * 2 + 1];
+        float sc = 1.f;
+        if (P.ss) sc = P.ss[(size_t)b * P.ss_stride + c] + 1.f;
+        const float ga = P.gamma[c], be = P.beta[c];
+        atomicAdd(P.d_gamma + c, sc * R1);
+        atomicAdd(P.d_beta + c, sc * R0);
+        if (P.dss) { P.dss[(size_t)b * 2 * C + c] = ga * R1 + be * R0; P.dss[(size_t)b * 2 * C + C + c] = R0; }
+        const int g = c / cpg;
+        atomicAdd(&s1[g], sc * ga * R0);
+        atomicAdd(&s2[g], sc * ga * R1);
+    }
+    __syncthreads();
+    if (tid < P.groups) {
+        const float n = (float)((double)P.pix_per_sample * cpg);
+        P.G[((size_t)b * P.groups + tid) * 2] = s1[tid] / n;
+        P.G[((size_t)b * P.groups + tid) * 2 + 1] = s2[tid] / n;
+    }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs P) {
+    __shared__ float mu[1024], rsd[1024], ta[1024], td[1024];
+    __shared__ float gm[64], gs[64];
+    const int tid = threadIdx.x, C = P.C, b = blockIdx.y;
+    NbTables T{mu, rsd, ta, td};
+    nb_build_tables(P, b, gm, T);
+    if (tid < 2 * P.groups) gs[tid] = P.G[(size_t)b * P.groups * 2 + tid];
+    __syncthreads();
+    const int cpg = C / P.groups;
+    const int LPP = P.lpp, ppb = 256 / LPP, sub = tid % LPP, pl = tid / LPP;
+    const float invC = 1.0f / (float)C;
+    for (long pix = (long)blockIdx.x * ppb + pl; pix < P.pix_per_sample; pix += (long)gridDim.x * ppb) {
+        const size_t base = ((size_t)b * P.pix_per_sample + pix) * C;
+        float4 da[VPL], rr[VPL];
+        float mean = 0.f, rstd = 0.f, m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c = (v * LPP + sub) * 4;
+            da[v] = rr[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) da[v] = *reinterpret_cast<const float4*>(P.dact + base + c);
+        }
+        if (P.r) {
+            float s = 0.f, ss = 0.f;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const int c = (v * LPP + sub) * 4;
+                if (c < C) {
+                    rr[v] = *reinterpret_cast<const float4*>(P.r + base + c);
+                    s += rr[v].x + rr[v].y + rr[v].z + rr[v].w;
+                    ss += rr[v].x * rr[v].x + rr[v].y * rr[v].y + rr[v].z * rr[v].z + rr[v].w * rr[v].w;
+                }
+            }
+            for (int o = 1; o < LPP; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+            mean = s * invC;
+            rstd = rsqrtf(fmaxf(ss * invC - mean * mean, 0.f) + NORM_EPS);
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                const int c = (v * LPP + sub) * 4;
+                if (c < C) {
+                    const float4 lg = *reinterpret_cast<const float4*>(P.ln_gamma + c);
+                    const float gd[4] = {lg.x * da[v].x, lg.y * da[v].y, lg.z * da[v].z, lg.w * da[v].w};
+                    const float rv[4] = {rr[v].x, rr[v].y, rr[v].z, rr[v].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { m1 += gd[e]; m2 += gd[e] * (rv[e] - mean) * rstd; }
+                }
+            }
+            for (int o = 1; o < LPP; o <<= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+            m1 *= invC; m2 *= invC;
+        }
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            const int c = (v * LPP + sub) * 4;
+            if (c < C) {
+                const float4 y = *reinterpret_cast<const float4*>(P.y + base + c);
+                const float yv[4] = {y.x, y.y, y.z, y.w}, dv[4] = {da[v].x, da[v].y, da[v].z, da[v].w};
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int g = (c + e) / cpg;
+                    const float z = fmaf(yv[e], ta[c + e], td[c + e]);
+                    const float dz = dv[e] * dsilu_f(z);
+                    const float xh = (yv[e] - mu[c + e]) * rsd[c + e];
+                    o[e] = ta[c + e] * dz - rsd[c + e] * (gs[2 * g] + xh * gs[2 * g + 1]);     // ta = rstd * gamma * (1+s)
+                }
+                *reinterpret_cast<float4*>(P.dy + base + c) = make_float4(o[0], o[1], o[2], o[3]);
+                if (P.r) {
+                    const float4 lg = *reinterpret_cast<const float4*>(P.ln_gamma + c);
+                    const float lgv[4] = {lg.x, lg.y, lg.z, lg.w}, rv[4] = {rr[v].x, rr[v].y, rr[v].z, rr[v].w};
+                    float d[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = rstd * (lgv[e] * dv[e] - m1 - (rv[e] - mean) * rstd * m2);
+                    *reinterpret_cast<float4*>(P.dr + base + c) = make_float4(d[0], d[1], d[2], d[3]);
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st) {
+    const int quads = a.C / 4;
+    int lpp = 1;
+    while (lpp < quads && lpp < 64) lpp <<= 1;
+    a.lpp = lpp;
+    const int vpl = (quads + lpp - 1) / lpp;
+    const int ppb = 256 / lpp;
+    const int gx = (int)std::max<long>(1, std::min<long>((a.pix_per_sample + ppb - 1) / ppb, 512));
+    hipError_t e = hipMemsetAsync(a.R, 0, (size_t)a.batch * a.C * 2 * 4, st);
+    if (e != hipSuccess) return e;
+    dim3 grid(gx, a.batch);
+    switch (vpl) {
+        case 1: hipLaunchKernelGGL(norm_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(norm_bwd_reduce_kernel<2>, grid, dim3(256), 0, st, a); break;
+        case 3: case 4: hipLaunchKernelGGL(norm_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(a.batch), dim3(256), 0, st, a);
+    const int gx2 = (int)std::max<long>(1, std::min<long>((a.pix_per_sample + ppb - 1) / ppb, 2048));
+    dim3 grid2(gx2, a.batch);
+    switch (vpl) {
+        case 1: hipLaunchKernelGGL(norm_bwd_apply_kernel<1>, grid2, dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(norm_bwd_apply_kernel<2>, grid2, dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(norm_bwd_apply_kernel<4>, grid2, dim3(256), 0, st, a); break;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace vdx

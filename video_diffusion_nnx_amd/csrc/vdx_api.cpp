@@ -347,6 +347,23 @@ int vdx_conv_backward_weights(const vdx_wgrad_desc* d, void* stream) {
     return VDX_OK;
 }
 
+int vdx_norm_act_backward(const float* dact, const float* y, float* dy, const double* stats, const float* gamma, const float* beta,
+                          int groups, const float* scale_shift, int scale_shift_stride, float* d_gamma, float* d_beta, float* dss,
+                          const float* r, const float* ln_gamma, float* dr, float* d_ln_gamma, float* d_ln_beta, float* scratch,
+                          int c, int batch, long pix_per_sample, void* stream) {
+    if (!dact || !y || !dy || !stats || !gamma || !beta || !d_gamma || !d_beta || !scratch) VDX_FAIL(VDX_ERR_INVALID, "norm_act_backward: null tensor");
+    if (r && (!ln_gamma || !dr || !d_ln_gamma || !d_ln_beta)) VDX_FAIL(VDX_ERR_INVALID, "norm_act_backward: incomplete LayerNorm branch");
+    if (c % 4 || c > 1024 || groups < 1 || groups > 32 || c % groups) VDX_FAIL(VDX_ERR_INVALID, "norm_act_backward: bad channels/groups");
+    vdx::NormBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.dact = dact; a.y = y; a.dy = dy; a.stats = stats; a.gamma = gamma; a.beta = beta; a.groups = groups;
+    a.ss = scale_shift; a.ss_stride = scale_shift_stride; a.d_gamma = d_gamma; a.d_beta = d_beta; a.dss = dss;
+    a.r = r; a.ln_gamma = ln_gamma; a.dr = dr; a.d_ln_gamma = d_ln_gamma; a.d_ln_beta = d_ln_beta;
+    a.R = scratch; a.G = scratch + (size_t)batch * c * 2; a.C = c; a.batch = batch; a.pix_per_sample = pix_per_sample;
+    VDX_HIP(vdx::launch_norm_bwd(a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
 int vdx_colsum(const float* x, float* out, long rows, int c, void* stream) {
     if (!x || !out || rows < 0 || c < 1 || c % 4) VDX_FAIL(VDX_ERR_INVALID, "colsum: bad argument");
     if (rows) VDX_HIP(vdx::launch_colsum(x, out, rows, c, (hipStream_t)stream));

@@ -123,6 +123,20 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st);
 hipError_t launch_colsum(const float* x, float* out, long rows, int C, hipStream_t st);
 hipError_t launch_add_inplace(float* y, const float* x, long n, hipStream_t st);
 
+// Backward of  act = SiLU((gamma*GN(y)+beta)*(1+s)+sh)  [+ LayerNorm_C(r) branch of the block tail]; channel-last [B][pix][C]
+struct NormBwdArgs {
+    const float* dact; const float* y; float* dy;                 // dL/dact (or dL/dout), saved pre-norm tensor, result dL/dy
+    const double* stats; const float* gamma; const float* beta; int groups;
+    const float* ss; int ss_stride;                               // forward scale/shift rows or null
+    float* d_gamma; float* d_beta;                                // accumulated (atomics)
+    float* dss;                                                   // [B][2C] (ds | dsh) written, or null
+    const float* r; const float* ln_gamma; float* dr; float* d_ln_gamma; float* d_ln_beta;   // LN branch (tail) or nulls
+    float* R; float* G;                                           // scratch: [B][C][2], [B][groups][2]
+    int C, batch; long pix_per_sample;
+    int lpp;
+};
+hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st);
+
 size_t conv_packed_bytes(int mode, int taps, int Cin, int Cout);
 int conv_cin_pad(int mode, int Cin);
 hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, int Cin, int Cout, hipStream_t st);
