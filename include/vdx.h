@@ -238,6 +238,18 @@ int vdx_norm_act_backward(const float* dact, const float* y, float* dy, const do
                           const float* r, const float* ln_gamma, float* dr, float* d_ln_gamma, float* d_ln_beta, float* scratch,
                           int c, int batch, long pix_per_sample, void* stream);
 
+/* Attention core backward (autodiff of modules.py:294-323 per sequence and head).  qkv [npix][3*heads*32] = x Wqkv + b
+ * (q unscaled), d_o [npix][heads*32] = dy Wo^T; writes o (attention output before the out projection), dq, dk, dv
+ * [npix][heads*32].  temporal != 0: sequences over F per (b,h,w), else over (h w) per (b,f). */
+int vdx_attention_core_backward(const float* qkv, const float* d_o, float* o, float* dq, float* dk, float* dv, int batch, int frames,
+                                int h, int w, int heads, int temporal, void* stream);
+
+/* SpatialLinearAttention core backward (autodiff of modules.py:105-118 per frame and head; heads = 8, D = 32).
+ * q, k, v, d_out [B*F*h*w][256]; writes o (pre to_out), dq, dk, dv.  scratch >= vdx_sla_backward_scratch_floats floats. */
+size_t vdx_sla_backward_scratch_floats(int nframes, int heads);
+int vdx_sla_core_backward(const float* q, const float* k, const float* v, const float* d_out, float* o, float* dq, float* dk, float* dv,
+                          float* scratch, int nframes, int npix, int heads, void* stream);
+
 /* out[c] += sum_rows x[row][c]  (bias gradients). */
 int vdx_colsum(const float* x, float* out, long rows, int c, void* stream);
 

@@ -135,3 +135,49 @@ def test_norm_act_backward(C, B, shape, use_ss, tail):
     if tail:
         assert _rel(res['dr'].cpu().double(), grads[i]) < 3e-5
         assert _rel(res['d_ln_gamma'].cpu().double(), grads[i + 1]) < 3e-5 and _rel(res['d_ln_beta'].cpu().double(), grads[i + 2]) < 3e-5
+
+
+@pytest.mark.parametrize('B,Fr,H,W,heads,temporal', [(1, 16, 4, 4, 8, True), (2, 10, 2, 3, 8, True), (1, 2, 8, 8, 8, False), (1, 3, 5, 5, 4, False)])
+def test_attention_core_backward(B, Fr, H, W, heads, temporal):
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(B + Fr + H)
+    D = torch.float64
+    HD = heads * 32
+    npix = B * Fr * H * W
+    qkv = torch.randn(npix, 3 * HD, generator=g, dtype=D).requires_grad_(True)
+    d_o = torch.randn(npix, HD, generator=g, dtype=D)
+    x = qkv.reshape(B, Fr, H * W, 3, heads, 32)
+    if temporal:
+        seq = x.permute(0, 2, 1, 3, 4, 5)            # b (hw) f ...
+    else:
+        seq = x                                       # b f (hw) ...
+    q, k, v = seq[..., 0, :, :] / 32 ** 0.5, seq[..., 1, :, :], seq[..., 2, :, :]
+    sim = torch.einsum('...ihd,...jhd->...hij', q, k)
+    o = torch.einsum('...hij,...jhd->...ihd', torch.softmax(sim, -1), v)
+    o_rows = (o.permute(0, 2, 1, 3, 4) if temporal else o).reshape(npix, HD)
+    (gqkv,) = torch.autograd.grad(o_rows, qkv, d_o)
+    og, dq, dk, dv = ops.attention_core_backward(qkv.detach().float().to(DEV), d_o.float().to(DEV), B, Fr, H, W, heads, temporal)
+    assert _rel(og.cpu().double(), o_rows.detach()) < 1e-5
+    got = torch.cat([dq, dk, dv], -1).cpu().double()
+    assert _rel(got, gqkv) < 2e-5, _rel(got, gqkv)
+
+
+@pytest.mark.parametrize('NF,H,W', [(2, 8, 8), (3, 5, 7), (1, 20, 20)])
+def test_sla_core_backward(NF, H, W):
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(NF + H)
+    D = torch.float64
+    N = H * W
+    q, k, v = [(2 * torch.randn(NF * N, 256, generator=g, dtype=D)).requires_grad_(True) for _ in range(3)]
+    d_out = torch.randn(NF * N, 256, generator=g, dtype=D)
+    def hs(t):
+        return t.reshape(NF, N, 8, 32).permute(0, 2, 3, 1)      # b h c n
+    qs, ks = torch.softmax(hs(q), -2), torch.softmax(hs(k), -1)
+    ctx = torch.einsum('bhdn,bhen->bhde', ks, hs(v))
+    out = torch.einsum('bhde,bhdn->bhen', ctx, qs).permute(0, 3, 1, 2).reshape(NF * N, 256)
+    gq, gk, gv = torch.autograd.grad(out, (q, k, v), d_out)
+    f = lambda t: t.detach().float().to(DEV)
+    o, dq, dk, dv = ops.sla_core_backward(f(q), f(k), f(v), f(d_out), NF, N)
+    assert _rel(o.cpu().double(), out.detach()) < 1e-5
+    for got, ref, nm in ((dq, gq, 'dq'), (dk, gk, 'dk'), (dv, gv, 'dv')):
+        assert _rel(got.cpu().double(), ref) < 3e-5, (nm, _rel(got.cpu().double(), ref))

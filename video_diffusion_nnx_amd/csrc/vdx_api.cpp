@@ -364,6 +364,32 @@ int vdx_norm_act_backward(const float* dact, const float* y, float* dy, const do
     return VDX_OK;
 }
 
+int vdx_attention_core_backward(const float* qkv, const float* d_o, float* o, float* dq, float* dk, float* dv, int batch, int frames,
+                                int h, int w, int heads, int temporal, void* stream) {
+    if (!qkv || !d_o || !o || !dq || !dk || !dv || heads < 1) VDX_FAIL(VDX_ERR_INVALID, "attention_core_backward: bad argument");
+    vdx::AttnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.qkv = qkv; a.dO = d_o; a.O = o; a.dq = dq; a.dk = dk; a.dv = dv; a.heads = heads; a.scale = 1.0f / sqrtf(32.0f);
+    const long hw = (long)h * w;
+    if (temporal) { a.L = frames; a.nseq = (long)batch * hw; a.inner = hw; a.outer_p = (long)frames * hw; a.tok_p = hw; }
+    else { a.L = (int)hw; a.nseq = (long)batch * frames; a.inner = 1; a.outer_p = hw; a.tok_p = 1; }
+    if (a.L > 64) VDX_FAIL(VDX_ERR_INVALID, "attention_core_backward: more than 64 tokens per sequence");
+    VDX_HIP(vdx::launch_attn_core_bwd(a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+size_t vdx_sla_backward_scratch_floats(int nframes, int heads) { return vdx::sla_bwd_scratch_floats(nframes, heads); }
+
+int vdx_sla_core_backward(const float* q, const float* k, const float* v, const float* d_out, float* o, float* dq, float* dk, float* dv,
+                          float* scratch, int nframes, int npix, int heads, void* stream) {
+    if (!q || !k || !v || !d_out || !o || !dq || !dk || !dv || !scratch || heads != 8) VDX_FAIL(VDX_ERR_INVALID, "sla_core_backward: bad argument");
+    vdx::SlaBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = q; a.k = k; a.v = v; a.dOut = d_out; a.O = o; a.dq = dq; a.dk = dk; a.dv = dv; a.A = scratch; a.NF = nframes; a.N = npix; a.heads = heads;
+    VDX_HIP(vdx::launch_sla_bwd(a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
 int vdx_colsum(const float* x, float* out, long rows, int c, void* stream) {
     if (!x || !out || rows < 0 || c < 1 || c % 4) VDX_FAIL(VDX_ERR_INVALID, "colsum: bad argument");
     if (rows) VDX_HIP(vdx::launch_colsum(x, out, rows, c, (hipStream_t)stream));

@@ -137,6 +137,20 @@ struct NormBwdArgs {
 };
 hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st);
 
+// attention core backward: qkv [npix][3*heads*32] (biased, q unscaled), dO [npix][heads*32] -> O, dq, dk, dv [npix][heads*32]
+struct AttnBwdArgs {
+    const float* qkv; const float* dO; float* O; float* dq; float* dk; float* dv;
+    int heads, L; long nseq, inner, outer_p, tok_p; float scale;
+};
+hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st);
+// SLA core backward: q,k,v,dOut [NF*N][256] -> O (forward, pre to_out), dq, dk, dv ; A = scratch (sla_bwd_scratch_floats)
+struct SlaBwdArgs {
+    const float* q; const float* k; const float* v; const float* dOut; float* O; float* dq; float* dk; float* dv; float* A;
+    int NF, N, heads;
+};
+size_t sla_bwd_scratch_floats(int NF, int heads);
+hipError_t launch_sla_bwd(const SlaBwdArgs& a, hipStream_t st);
+
 size_t conv_packed_bytes(int mode, int taps, int Cin, int Cout);
 int conv_cin_pad(int mode, int Cin);
 hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, int Cin, int Cout, hipStream_t st);

@@ -194,3 +194,21 @@ def norm_act_backward(dact, y, stats, gamma, beta, groups=8, scale_shift=None, r
                       L.ptr(r), L.ptr(ln_gamma), L.ptr(out['dr']), L.ptr(out['d_ln_gamma']), L.ptr(out['d_ln_beta']), L.ptr(scratch),
                       Cc, B, pix, L.stream_ptr()))
     return out
+
+
+_attn_core_bwd = L._sig('vdx_attention_core_backward', C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p])
+_sla_scr = L._sig('vdx_sla_backward_scratch_floats', C.c_size_t, [C.c_int, C.c_int])
+_sla_core_bwd = L._sig('vdx_sla_core_backward', C.c_int, [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_void_p])
+
+
+def attention_core_backward(qkv, d_o, B, Fr, H, W, heads, temporal):
+    outs = [torch.empty_like(d_o) for _ in range(4)]
+    L.check(_attn_core_bwd(L.ptr(qkv), L.ptr(d_o), *[L.ptr(t) for t in outs], B, Fr, H, W, heads, int(temporal), L.stream_ptr()))
+    return outs      # o, dq, dk, dv
+
+
+def sla_core_backward(q, k, v, d_out, nframes, npix, heads=8):
+    outs = [torch.empty_like(q) for _ in range(4)]
+    scr = torch.empty(_sla_scr(nframes, heads), dtype=torch.float32, device=q.device)
+    L.check(_sla_core_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(d_out), *[L.ptr(t) for t in outs], L.ptr(scr), nframes, npix, heads, L.stream_ptr()))
+    return outs      # o, dq, dk, dv
