@@ -257,6 +257,20 @@ int vdx_colsum(const float* x, float* out, long rows, int c, void* stream);
  * Train step (reference trainer.py:322-392).
  * ---------------------------------------------------------------------------------------------- */
 
+/* Unet3D backward (jax.value_and_grad of unet3d.py:262-387, reference trainer.py:361).  Must follow a vdx_unet_forward of the
+ * same inputs on the same fwd_workspace (every intermediate is read back from its slot).  The reverse walk is cut in
+ * vdx_num_stages() stages (head = num_stages-1, ups, mid, downs, stem = 0) so that the caller can all-reduce finished
+ * gradient buckets while earlier stages still run: call with descending, contiguous [stage_hi .. stage_lo] ranges, starting
+ * at the head (which zeroes `grads`).  grads: flat fp32, same layout as params (vdx_param_info).
+ * packed_t: vdx_pack_params_bwd (transposed packing for the data gradients). */
+int vdx_num_stages(const vdx_handle* h);
+size_t vdx_packed_bwd_bytes(const vdx_handle* h);
+int vdx_pack_params_bwd(const vdx_handle* h, const float* params, void* packed_t, void* stream);
+size_t vdx_bwd_workspace_bytes(const vdx_handle* h, int batch);
+int vdx_unet_backward(vdx_handle* h, const float* params, const void* packed, const void* packed_t, const float* x, const int* time,
+                      const float* cond, const unsigned char* cond_mask, int null_all, const float* d_out, void* fwd_workspace,
+                      void* bwd_workspace, size_t bwd_workspace_bytes, float* grads, int stage_hi, int stage_lo, int batch, void* stream);
+
 /* d(mean loss)/d(eps_hat) for the l1 / l2 loss of gaussian_diffusion.py:463-466, written channel-last like eps_hat. */
 int vdx_loss_grad(const float* eps_hat, const float* noise, float* d_eps_hat, int batch, int channels, long fhw, int l2, void* stream);
 

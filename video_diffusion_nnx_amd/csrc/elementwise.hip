@@ -230,7 +230,7 @@ hipError_t launch_time_mlp(const TimeMlpArgs& a, int B, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void resblock_ss_kernel(const float* __restrict__ params, const float* __restrict__ temb,
                                                           const SsLayer* __restrict__ layers, float* __restrict__ ss_base,
-                                                          int temb_dim, int B) {
+                                                          float* __restrict__ lin_base, int temb_dim, int B) {
     extern __shared__ float sm[];                  // act[temb_dim] | red[16]
     float* act = sm;
     float* red = sm + temb_dim;
@@ -264,17 +264,18 @@ __global__ __launch_bounds__(256) void resblock_ss_kernel(const float* __restric
     const float* g = params + L.g_off;
     const float* be = params + L.be_off;
     float* out = ss_base + (size_t)L.out_off * B + (size_t)b * N;
+    float* lin = lin_base ? lin_base + (size_t)L.out_off * B + (size_t)b * N : nullptr;     // pre-LayerNorm values, kept for the backward
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int n = tid + 256 * j;
-        if (n < N) out[n] = fmaf((v[j] - mean) * rstd, g[n], be[n]);
+        if (n < N) { out[n] = fmaf((v[j] - mean) * rstd, g[n], be[n]); if (lin) lin[n] = v[j]; }
     }
 }
 
 hipError_t launch_resblock_ss(const float* params, const float* temb, const SsLayer* layers, int nlayers, float* ss_base,
-                              int temb_dim, int B, hipStream_t st) {
+                              float* lin_base, int temb_dim, int B, hipStream_t st) {
     hipLaunchKernelGGL(resblock_ss_kernel, dim3(B, nlayers), dim3(256), (size_t)(temb_dim + 16) * 4, st, params, temb, layers,
-                       ss_base, temb_dim, B);
+                       ss_base, lin_base, temb_dim, B);
     return hipGetLastError();
 }
 

@@ -14,12 +14,13 @@ struct ResP {
     int cin = 0, cout = 0; bool has_mlp = false, has_res = false; int ss_index = -1;
     long mlp_w = 0, mlp_b = 0, n1_s, n1_b, b1_w, b1_b, b1_gs, b1_gb, b2_w, b2_b, b2_gs, b2_gb, rc_w, rc_b, n2_s, n2_b;   // float offsets
     size_t pk_b1, pk_b2, pk_rc;                                                                               // packed byte offsets
+    size_t pt_b1 = 0, pt_b2 = 0, pt_rc = 0;                                                                   // transposed packing (backward)
     int s_y1, s_y2, s_rc, s_out, st1, st2;                                                                    // workspace slots / stats slabs
 };
-struct AttnP { std::string name; int C; long norm_s, norm_b, w[3], b[3], o_w, o_b; size_t pk_qkv, pk_bqkv, pk_o; };
-struct SlaP { std::string name; int C; long norm_s, norm_b, w[3], o_w; size_t pk[3], pk_o; };
+struct AttnP { std::string name; int C; long norm_s, norm_b, w[3], b[3], o_w, o_b; size_t pk_qkv, pk_bqkv, pk_o; size_t pt_w[3], pt_o; };
+struct SlaP { std::string name; int C; long norm_s, norm_b, w[3], o_w; size_t pk[3], pk_o; size_t pt_w[3], pt_o; };
 struct Level {
-    int cin, cout, lvl; ResP res0, res1; bool has_sla; SlaP sla; AttnP attn; bool has_resample; long rs_w, rs_b; size_t pk_rs;
+    int cin, cout, lvl; ResP res0, res1; bool has_sla; SlaP sla; AttnP attn; bool has_resample; long rs_w, rs_b; size_t pk_rs; size_t pt_rs = 0;
     int s_sla, s_attn, s_rs;
 };
 
@@ -28,6 +29,7 @@ struct Model {
     int mode, init_dim, out_dim, time_dim, temb_dim;
     std::vector<ParamInfo> params; long param_total = 0;
     size_t packed_bytes = 0;
+    size_t packed_t_bytes = 0;
     std::vector<Slot> slots; long act_floats_per_sample = 0;
     std::vector<SsLayer> ss_layers; long ss_floats_per_sample = 0; SsLayer* d_ss_layers = nullptr;
     int n_stats = 0;
@@ -42,6 +44,15 @@ struct Model {
 int model_build(Model* m);
 size_t model_workspace_bytes(const Model* m, int B);
 hipError_t model_pack(const Model* m, const float* params, void* packed, hipStream_t st);
+size_t model_bwd_workspace_bytes(const Model* m, int B);
+hipError_t model_pack_t(const Model* m, const float* params, void* packed_t, hipStream_t st);
+// Reverse pass over stages [stage_lo, stage_hi] (descending; 2n+2 = head ... 0 = stem).  A full pass calls the stages in
+// order; `state` carries the running activation gradient between calls.
+struct BwdState { float* g = nullptr; int next_stage = -1; };
+int model_backward(const Model* m, BwdState* state, const float* params, const void* packed, const void* packed_t, const float* x,
+                   const int* time, const float* cond, const unsigned char* cond_mask, int null_all, const float* d_out,
+                   void* fwd_workspace, void* bwd_workspace, size_t bwd_workspace_bytes, float* grads, int stage_hi, int stage_lo,
+                   int B, hipStream_t st);
 int model_forward(const Model* m, const float* params, const void* packed, const float* x, const int* time,
                   const float* cond, const unsigned char* cond_mask, int null_all, float* out, void* workspace,
                   size_t workspace_bytes, int B, hipStream_t st);

@@ -29,6 +29,12 @@ static long add_param(Model* m, const std::string& name, std::initializer_list<l
     return p.offset;
 }
 
+static size_t add_packed_t(Model* m, size_t bytes) {
+    const size_t off = m->packed_t_bytes;
+    m->packed_t_bytes += (bytes + 255) / 256 * 256;
+    return off;
+}
+
 static size_t add_packed(Model* m, size_t bytes) {
     const size_t off = m->packed_bytes;
     m->packed_bytes += (bytes + 255) / 256 * 256;
@@ -61,6 +67,9 @@ static ResP make_res(Model* m, const std::string& pre, int cin, int cout, bool h
     r.pk_b1 = add_packed(m, conv_packed_bytes(m->mode, 9, cin, cout));
     r.pk_b2 = add_packed(m, conv_packed_bytes(m->mode, 9, cout, cout));
     if (r.has_res) r.pk_rc = add_packed(m, conv_packed_bytes(m->mode, 1, cin, cout));
+    r.pt_b1 = add_packed_t(m, conv_packed_bytes(m->mode, 9, cout, cin));
+    r.pt_b2 = add_packed_t(m, conv_packed_bytes(m->mode, 9, cout, cout));
+    if (r.has_res) r.pt_rc = add_packed_t(m, conv_packed_bytes(m->mode, 1, cout, cin));
     if (has_mlp) {
         r.ss_index = (int)m->ss_layers.size();
         SsLayer L;
@@ -90,6 +99,8 @@ static AttnP make_attn(Model* m, const std::string& pre, int C) {
     a.pk_qkv = add_packed(m, 3 * conv_packed_bytes(m->mode, 1, C, H * D));
     a.pk_bqkv = add_packed(m, (size_t)3 * H * D * 4);
     a.pk_o = add_packed(m, conv_packed_bytes(m->mode, 1, H * D, C));
+    for (int i = 0; i < 3; ++i) a.pt_w[i] = add_packed_t(m, conv_packed_bytes(m->mode, 1, H * D, C));      // [C rows][HD]
+    a.pt_o = add_packed_t(m, conv_packed_bytes(m->mode, 1, C, H * D));                                       // [HD rows][C]
     a.name = pre;
     return a;
 }
@@ -107,6 +118,8 @@ static SlaP make_sla(Model* m, const std::string& pre, int C) {
     }
     s.o_w = add_param(m, pre + ".fn.fn.to_out.kernel", {1, HD, C});
     s.pk_o = add_packed(m, conv_packed_bytes(m->mode, 1, HD, C));
+    for (int i = 0; i < 3; ++i) s.pt_w[i] = add_packed_t(m, conv_packed_bytes(m->mode, 1, HD, C));
+    s.pt_o = add_packed_t(m, conv_packed_bytes(m->mode, 1, C, HD));
     s.name = pre;
     return s;
 }
@@ -176,6 +189,7 @@ int model_build(Model* m) {
             L.rs_w = add_param(m, pre + ".4.kernel", {1, 4, 4, dims[i + 1], dims[i + 1]});
             L.rs_b = add_param(m, pre + ".4.bias", {dims[i + 1]});
             L.pk_rs = add_packed(m, conv_packed_bytes(m->mode, 16, dims[i + 1], dims[i + 1]));
+            L.pt_rs = add_packed_t(m, conv_packed_bytes(m->mode, 16, dims[i + 1], dims[i + 1]));
         }
     }
     const int mid = dims[nl];
@@ -198,6 +212,7 @@ int model_build(Model* m) {
             L.rs_w = add_param(m, pre + ".4.kernel", {1, 4, 4, din, din});
             L.rs_b = add_param(m, pre + ".4.bias", {din});
             L.pk_rs = add_packed(m, conv_packed_bytes(m->mode, 16, din, din));
+            L.pt_rs = add_packed_t(m, conv_packed_bytes(m->mode, 16, din, din));
         }
     }
     m->fin = make_res(m, "final_conv.layers.0", 2 * c.dim, c.dim, false);
@@ -247,7 +262,7 @@ size_t model_workspace_bytes(const Model* m, int B) {
     size_t b = 0;
     b += ((size_t)m->act_floats_per_sample * B * 4 + 255) / 256 * 256;
     b += ((size_t)m->temb_dim * B * 4 + 255) / 256 * 256;
-    b += ((size_t)m->ss_floats_per_sample * B * 4 + 255) / 256 * 256;
+    b += 2 * (((size_t)m->ss_floats_per_sample * B * 4 + 255) / 256 * 256);       // scale/shift + pre-LayerNorm values
     b += ((size_t)m->n_stats * B * GN_SLOTS * m->cfg.resnet_groups * 2 * 8 + 255) / 256 * 256;
     b += (m->sla_ws_bytes_per_sample * B + 255) / 256 * 256;
     return b;
@@ -314,7 +329,7 @@ hipError_t model_pack(const Model* m, const float* p, void* packed, hipStream_t 
 
 struct Fwd {
     const Model* m; const float* p; const char* pk; int B; hipStream_t st;
-    float* act; float* temb; float* ss; double* stats; char* sla_ws;
+    float* act; float* temb; float* ss; float* ss_lin; double* stats; char* sla_ws;
     float* slot(int s) const { return act + (size_t)m->slots[s].offset_per_sample * B; }
     double* stat(int i) const { return stats + (size_t)i * B * GN_SLOTS * m->cfg.resnet_groups * 2; }
 };
@@ -410,6 +425,7 @@ int model_forward(const Model* m, const float* params, const void* packed, const
     f.act = reinterpret_cast<float*>(w); w += ((size_t)m->act_floats_per_sample * B * 4 + 255) / 256 * 256;
     f.temb = reinterpret_cast<float*>(w); w += ((size_t)m->temb_dim * B * 4 + 255) / 256 * 256;
     f.ss = reinterpret_cast<float*>(w); w += ((size_t)m->ss_floats_per_sample * B * 4 + 255) / 256 * 256;
+    f.ss_lin = reinterpret_cast<float*>(w); w += ((size_t)m->ss_floats_per_sample * B * 4 + 255) / 256 * 256;
     f.stats = reinterpret_cast<double*>(w);
     const size_t stats_bytes = (size_t)m->n_stats * B * GN_SLOTS * c.resnet_groups * 2 * 8;
     w += (stats_bytes + 255) / 256 * 256;
@@ -426,7 +442,7 @@ int model_forward(const Model* m, const float* params, const void* packed, const
         t.dim = c.dim; t.time_dim = m->time_dim; t.cond = cond; t.null_cond_emb = c.cond_dim ? params + m->null_cond : nullptr;
         t.cond_mask = cond_mask; t.null_all = null_all; t.cond_dim = c.cond_dim; t.temb = f.temb; t.temb_dim = m->temb_dim;
         VDX_E(launch_time_mlp(t, B, st));
-        VDX_E(launch_resblock_ss(params, f.temb, m->d_ss_layers, (int)m->ss_layers.size(), f.ss, m->temb_dim, B, st));
+        VDX_E(launch_resblock_ss(params, f.temb, m->d_ss_layers, (int)m->ss_layers.size(), f.ss, f.ss_lin, m->temb_dim, B, st));
     }
     // init conv + init temporal attention   (unet3d.py:280-286)
     VDX_E(launch_init_conv(x, params + m->init_w, params + m->init_b, f.slot(m->s_init), B, c.channels, Fr, S0, S0, m->init_dim, c.init_kernel_size, st));

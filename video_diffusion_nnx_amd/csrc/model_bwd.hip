@@ -1,0 +1,363 @@
+// Reverse pass of the Unet3D hot path (host orchestration).  Mirrors model.hip's forward walk backwards
+// (reference: jax.value_and_grad over unet3d.py:262-387, trainer.py:361).  Every GEMM-shaped step reuses the forward
+// launchers: data gradients = conv_igemm with transposed/flipped packed weights, weight gradients = conv_wgrad,
+// projections of the attention blocks = 1x1 convs around the small per-sequence cores (attn_bwd.hip).
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+#include "vdx_common.h"
+#include "vdx_internal.h"
+#include "model.h"
+
+namespace vdx {
+
+namespace {
+
+struct LevelBufs { float* ga; float* gb; float* t1; float* t2; float* t3; float* gskip; };
+
+struct Bwd {
+    const Model* m; const float* p; const char* pk; const char* pt; float* grads; int B; hipStream_t st;
+    // forward workspace views
+    float* act; float* temb; float* ss; float* ss_lin; double* stats;
+    // backward workspace views
+    std::vector<LevelBufs> lv; float* gr; float* S; float* dss; float* dtemb; float* normscr; float* sla_a;
+    float* slot(int s) const { return act + (size_t)m->slots[s].offset_per_sample * B; }
+    double* stat(int i) const { return stats + (size_t)i * B * GN_SLOTS * m->cfg.resnet_groups * 2; }
+    long pix(int lvl) const { const long s = m->cfg.image_size >> lvl; return (long)m->cfg.num_frames * s * s; }
+    int size(int lvl) const { return m->cfg.image_size >> lvl; }
+    hipError_t err = hipSuccess;
+    bool ok(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; return e == hipSuccess; }
+};
+
+size_t lvl_width(const Model* m, int l) { return (size_t)m->cfg.dim * m->cfg.dim_mults[l]; }
+
+// data gradient through a conv: out[.., cin_rows] = conv(dy; transposed packing rows [row0, row0+nrows)) (+ res)
+void dgrad(Bwd& b, const float* dy, int Cdy, const void* wpt, int rows_total, int row0, int nrows, int lvl_in, int kind_fwd, int k,
+           int stride_fwd, const float* res, float* out) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x0 = dy; a.C0 = Cdy; a.wp = wpt; a.y = out; a.Cout = nrows; a.wrows = rows_total; a.wrow0 = row0; a.res = res;
+    a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames;
+    // lvl_in = level of the FORWARD conv's input; dy lives at the forward output resolution
+    if (kind_fwd == 0 && stride_fwd == 1) { a.H = a.W = b.size(lvl_in); a.kind = 0; a.kh = a.kw = k; a.stride = 1; a.pad = (k - 1) / 2; }
+    else if (kind_fwd == 0) { a.H = a.W = b.size(lvl_in + 1); a.kind = 1; a.kh = a.kw = 4; a.stride = 1; }                      // Downsample -> ConvTranspose
+    else { a.H = a.W = b.size(lvl_in - 1); a.kind = 0; a.kh = a.kw = 4; a.stride = 2; a.pad = 1; }                               // Upsample -> stride-2 conv
+    b.ok(launch_conv(b.m->mode, a, b.st));
+}
+
+void wgrad(Bwd& b, const float* x0, int c0, const float* x1, int c1, const float* dy, int Cout, long w_off, int lvl_in, int kind, int k, int stride,
+           const double* in_stats = nullptr, const float* gamma = nullptr, const float* beta = nullptr, const float* ss = nullptr, int ss_stride = 0) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x0 = x0; a.x1 = x1; a.C0 = c0; a.C1 = c1; a.dy = dy; a.Cout = Cout; a.dW = b.grads + w_off;
+    a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl_in);
+    a.kind = kind; a.kh = a.kw = kind ? 4 : k; a.stride = kind ? 1 : stride;
+    if (in_stats) { a.pro = 1; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta; a.groups = b.m->cfg.resnet_groups; a.ss = ss; a.ss_stride = ss_stride; }
+    b.ok(launch_conv_wgrad(a, b.st));
+}
+
+void colsum(Bwd& b, const float* x, long rows, int C, long off) { b.ok(launch_colsum(x, b.grads + off, rows, C, b.st)); }
+
+// ResnetBlock backward.  g = dL/d(out) [pix][cout]; writes dL/d(x0) to out0 ([pix][c0]) and dL/d(x1) to out1 ([pix][c1], if c1)
+void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, const float* x1, int c1, int lvl, float* out0, float* out1) {
+    const Model* m = b.m;
+    const int G = m->cfg.resnet_groups;
+    const long npix = b.pix(lvl) * b.B;
+    LevelBufs& L = b.lv[lvl];
+    const float* rsrc = r.has_res ? b.slot(r.s_rc) : x0;
+    // 1. tail: out = SiLU(GN2(y2)) + LN(r)
+    NormBwdArgs t;
+    memset(&t, 0, sizeof(t));
+    t.dact = g; t.y = b.slot(r.s_y2); t.dy = L.t1; t.stats = b.stat(r.st2); t.gamma = b.p + r.b2_gs; t.beta = b.p + r.b2_gb; t.groups = G;
+    t.d_gamma = b.grads + r.b2_gs; t.d_beta = b.grads + r.b2_gb;
+    t.r = rsrc; t.ln_gamma = b.p + r.n2_s; t.dr = L.t2; t.d_ln_gamma = b.grads + r.n2_s; t.d_ln_beta = b.grads + r.n2_b;
+    t.R = b.normscr; t.G = b.normscr + (size_t)b.B * r.cout * 2; t.C = r.cout; t.batch = b.B; t.pix_per_sample = b.pix(lvl);
+    b.ok(launch_norm_bwd(t, b.st));
+    // 2. conv2: y2 = conv(SiLU(GN1(y1)*(1+s)+sh))
+    const float* ssrow = r.has_mlp ? b.ss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
+    wgrad(b, b.slot(r.s_y1), r.cout, nullptr, 0, L.t1, r.cout, r.b2_w, lvl, 0, 3, 1, b.stat(r.st1), b.p + r.b1_gs, b.p + r.b1_gb, ssrow, 2 * r.cout);
+    colsum(b, L.t1, npix, r.cout, r.b2_b);
+    dgrad(b, L.t1, r.cout, b.pt + r.pt_b2, r.cout, 0, r.cout, lvl, 0, 3, 1, nullptr, L.t3);            // dL/d(act1)
+    // 3. prologue: act1 = SiLU((GN1(y1))*(1+s)+sh)
+    NormBwdArgs q;
+    memset(&q, 0, sizeof(q));
+    q.dact = L.t3; q.y = b.slot(r.s_y1); q.dy = L.t1; q.stats = b.stat(r.st1); q.gamma = b.p + r.b1_gs; q.beta = b.p + r.b1_gb; q.groups = G;
+    q.ss = ssrow; q.ss_stride = 2 * r.cout; q.d_gamma = b.grads + r.b1_gs; q.d_beta = b.grads + r.b1_gb;
+    q.dss = r.has_mlp ? b.dss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
+    q.R = b.normscr; q.G = b.normscr + (size_t)b.B * r.cout * 2; q.C = r.cout; q.batch = b.B; q.pix_per_sample = b.pix(lvl);
+    b.ok(launch_norm_bwd(q, b.st));                                                                    // t1 = dL/d(y1)
+    // 4. conv1 + residual branch
+    wgrad(b, x0, c0, x1, c1, L.t1, r.cout, r.b1_w, lvl, 0, 3, 1);
+    colsum(b, L.t1, npix, r.cout, r.b1_b);
+    const int cin = c0 + c1;
+    if (r.has_res) {
+        wgrad(b, x0, c0, x1, c1, L.t2, r.cout, r.rc_w, lvl, 0, 1, 1);
+        colsum(b, L.t2, npix, r.cout, r.rc_b);
+        dgrad(b, L.t2, r.cout, b.pt + r.pt_rc, cin, 0, c0, lvl, 0, 1, 1, nullptr, L.t3);
+        dgrad(b, L.t1, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t3, out0);
+        if (c1) {
+            dgrad(b, L.t2, r.cout, b.pt + r.pt_rc, cin, c0, c1, lvl, 0, 1, 1, nullptr, L.t3);
+            dgrad(b, L.t1, r.cout, b.pt + r.pt_b1, cin, c0, c1, lvl, 0, 3, 1, L.t3, out1);
+        }
+    } else {
+        dgrad(b, L.t1, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t2, out0);                   // identity residual: + dL/d(r)
+    }
+}
+
+// 1x1 projection  y[pix][cout] = x[pix][cin] . W (+bias) (+res)  with a packed weight
+void proj(Bwd& b, const float* x, int cin, const void* wp, const float* bias, int cout, int lvl, const float* res, float* y) {
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x0 = x; a.C0 = cin; a.wp = wp; a.bias = bias; a.y = y; a.Cout = cout; a.res = res;
+    a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
+    a.kind = 0; a.kh = a.kw = 1; a.stride = 1; a.pad = 0;
+    b.ok(launch_conv(b.m->mode, a, b.st));
+}
+
+void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w_off, int lvl) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x0 = x; a.C0 = cin; a.dy = dy; a.Cout = cout; a.dW = b.grads + w_off;
+    a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
+    a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
+    b.ok(launch_conv_wgrad(a, b.st));
+}
+
+// y = MHA(x) + x  backward: g = dL/dy -> out = dL/dx
+void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, bool temporal, float* out) {
+    const Model* m = b.m;
+    const int C = ap.C, H = m->cfg.attn_heads, HD = H * 32;
+    const long npix = b.pix(lvl) * b.B;
+    float* qkv = b.S; float* dO = qkv + npix * 3 * HD; float* O = dO + npix * HD; float* dq = O + npix * HD; float* dk = dq + npix * HD; float* dv = dk + npix * HD;
+    LevelBufs& L = b.lv[lvl];
+    proj(b, x, C, b.pk + ap.pk_qkv, reinterpret_cast<const float*>(b.pk + ap.pk_bqkv), 3 * HD, lvl, nullptr, qkv);
+    proj(b, g, C, b.pt + ap.pt_o, nullptr, HD, lvl, nullptr, dO);                                    // dO = g . Wo^T
+    AttnBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.qkv = qkv; a.dO = dO; a.O = O; a.dq = dq; a.dk = dk; a.dv = dv; a.heads = H; a.scale = 1.0f / sqrtf((float)m->cfg.attn_dim_head);
+    const long hw = (long)b.size(lvl) * b.size(lvl), Fr = m->cfg.num_frames;
+    if (temporal) { a.L = (int)Fr; a.nseq = b.B * hw; a.inner = hw; a.outer_p = Fr * hw; a.tok_p = hw; }
+    else { a.L = (int)hw; a.nseq = b.B * Fr; a.inner = 1; a.outer_p = hw; a.tok_p = 1; }
+    b.ok(launch_attn_core_bwd(a, b.st));
+    wgrad1x1(b, O, HD, g, C, ap.o_w, lvl);
+    colsum(b, g, npix, C, ap.o_b);
+    float* d3[3] = {dq, dk, dv};
+    for (int i = 0; i < 3; ++i) { wgrad1x1(b, x, C, d3[i], HD, ap.w[i], lvl); colsum(b, d3[i], npix, HD, ap.b[i]); }
+    proj(b, dq, HD, b.pt + ap.pt_w[0], nullptr, C, lvl, g, L.t1);
+    proj(b, dk, HD, b.pt + ap.pt_w[1], nullptr, C, lvl, L.t1, L.t2);
+    proj(b, dv, HD, b.pt + ap.pt_w[2], nullptr, C, lvl, L.t2, out);
+}
+
+void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, float* out) {
+    const Model* m = b.m;
+    const int C = sp.C, HD = m->cfg.attn_heads * 32;
+    const long npix = b.pix(lvl) * b.B;
+    float* q = b.S; float* k = q + npix * HD; float* v = k + npix * HD; float* dOut = v + npix * HD; float* O = dOut + npix * HD;
+    float* dq = O + npix * HD; float* dk = dq + npix * HD; float* dv = dk + npix * HD;
+    LevelBufs& L = b.lv[lvl];
+    proj(b, x, C, b.pk + sp.pk[0], nullptr, HD, lvl, nullptr, q);
+    proj(b, x, C, b.pk + sp.pk[1], nullptr, HD, lvl, nullptr, k);
+    proj(b, x, C, b.pk + sp.pk[2], nullptr, HD, lvl, nullptr, v);
+    proj(b, g, C, b.pt + sp.pt_o, nullptr, HD, lvl, nullptr, dOut);
+    SlaBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = q; a.k = k; a.v = v; a.dOut = dOut; a.O = O; a.dq = dq; a.dk = dk; a.dv = dv; a.A = b.sla_a;
+    a.NF = b.B * m->cfg.num_frames; a.N = b.size(lvl) * b.size(lvl); a.heads = m->cfg.attn_heads;
+    b.ok(launch_sla_bwd(a, b.st));
+    wgrad1x1(b, O, HD, g, C, sp.o_w, lvl);
+    float* d3[3] = {dq, dk, dv};
+    for (int i = 0; i < 3; ++i) wgrad1x1(b, x, C, d3[i], HD, sp.w[i], lvl);
+    proj(b, dq, HD, b.pt + sp.pt_w[0], nullptr, C, lvl, g, L.t1);
+    proj(b, dk, HD, b.pt + sp.pt_w[1], nullptr, C, lvl, L.t1, L.t2);
+    proj(b, dv, HD, b.pt + sp.pt_w[2], nullptr, C, lvl, L.t2, out);
+}
+
+float* other(const LevelBufs& L, const float* cur) { return cur == L.ga ? L.gb : L.ga; }
+
+}  // namespace
+
+static size_t al(size_t floats) { return (floats + 63) / 64 * 64; }
+
+size_t model_bwd_workspace_bytes(const Model* m, int B) {
+    const int nl = m->cfg.n_mults;
+    size_t fl = 0;
+    for (int l = 0; l < nl; ++l) {
+        const long s = m->cfg.image_size >> l;
+        fl += 6 * al((size_t)B * m->cfg.num_frames * s * s * std::max<size_t>(lvl_width(m, l), m->init_dim));
+    }
+    const size_t pix0 = (size_t)B * m->cfg.num_frames * m->cfg.image_size * m->cfg.image_size;
+    fl += al(pix0 * m->init_dim);                                  // gr
+    fl += al(pix0 * (size_t)(m->cfg.attn_heads * 32) * 8);         // S
+    fl += al((size_t)m->ss_floats_per_sample * B);                 // dss
+    fl += al((size_t)m->temb_dim * B);                             // dtemb
+    fl += al((size_t)B * (2 * 1024 + 64));                         // norm scratch
+    fl += al(sla_bwd_scratch_floats(B * m->cfg.num_frames, m->cfg.attn_heads));
+    return fl * 4;
+}
+
+hipError_t model_pack_t(const Model* m, const float* p, void* packed_t, hipStream_t st) {
+    char* pt = reinterpret_cast<char*>(packed_t);
+    hipError_t e;
+    const int HD = m->cfg.attn_heads * 32;
+#define VDX_E(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
+    auto res = [&](const ResP& r) -> hipError_t {
+        VDX_E(launch_pack_weights_t(m->mode, p + r.b1_w, pt + r.pt_b1, 9, r.cin, r.cout, st));
+        VDX_E(launch_pack_weights_t(m->mode, p + r.b2_w, pt + r.pt_b2, 9, r.cout, r.cout, st));
+        if (r.has_res) VDX_E(launch_pack_weights_t(m->mode, p + r.rc_w, pt + r.pt_rc, 1, r.cin, r.cout, st));
+        return hipSuccess;
+    };
+    auto attn = [&](const AttnP& a) -> hipError_t {
+        for (int i = 0; i < 3; ++i) VDX_E(launch_pack_weights_t(m->mode, p + a.w[i], pt + a.pt_w[i], 1, a.C, HD, st));
+        VDX_E(launch_pack_weights_t(m->mode, p + a.o_w, pt + a.pt_o, 1, HD, a.C, st));
+        return hipSuccess;
+    };
+    auto sla = [&](const SlaP& s) -> hipError_t {
+        for (int i = 0; i < 3; ++i) VDX_E(launch_pack_weights_t(m->mode, p + s.w[i], pt + s.pt_w[i], 1, s.C, HD, st));
+        VDX_E(launch_pack_weights_t(m->mode, p + s.o_w, pt + s.pt_o, 1, HD, s.C, st));
+        return hipSuccess;
+    };
+    VDX_E(attn(m->init_attn));
+    for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<Level>& lv = pass ? m->ups : m->downs;
+        for (const Level& L : lv) {
+            VDX_E(res(L.res0)); VDX_E(res(L.res1));
+            if (L.has_sla) VDX_E(sla(L.sla));
+            VDX_E(attn(L.attn));
+            if (L.has_resample) VDX_E(launch_pack_weights_t(m->mode, p + L.rs_w, pt + L.pt_rs, 16, L.cout, L.cout, st));
+        }
+    }
+    VDX_E(res(m->mid1)); VDX_E(attn(m->mid_sattn)); VDX_E(attn(m->mid_tattn)); VDX_E(res(m->mid2)); VDX_E(res(m->fin));
+#undef VDX_E
+    return hipSuccess;
+}
+
+int model_backward(const Model* m, BwdState* state, const float* params, const void* packed, const void* packed_t, const float* x,
+                   const int* time, const float* cond, const unsigned char* cond_mask, int null_all, const float* d_out,
+                   void* fwd_workspace, void* bwd_workspace, size_t bwd_workspace_bytes, float* grads, int stage_hi, int stage_lo,
+                   int B, hipStream_t st) {
+    const vdx_config& c = m->cfg;
+    const int nl = c.n_mults, top = 2 * nl + 2;
+    if (stage_hi > top || stage_lo < 0 || stage_lo > stage_hi) return vdx_set_error(VDX_ERR_INVALID, "backward: bad stage range", __FILE__, __LINE__);
+    if (bwd_workspace_bytes < model_bwd_workspace_bytes(m, B)) return vdx_set_error(VDX_ERR_NOMEM, "backward: workspace too small", __FILE__, __LINE__);
+    if (stage_hi != top && state->next_stage != stage_hi) return vdx_set_error(VDX_ERR_STATE, "backward: stages must be run in descending order from the head", __FILE__, __LINE__);
+    Bwd b;
+    b.m = m; b.p = params; b.pk = reinterpret_cast<const char*>(packed); b.pt = reinterpret_cast<const char*>(packed_t);
+    b.grads = grads; b.B = B; b.st = st;
+    {   // forward workspace carve (must match model_forward)
+        char* w = reinterpret_cast<char*>(fwd_workspace);
+        b.act = reinterpret_cast<float*>(w); w += ((size_t)m->act_floats_per_sample * B * 4 + 255) / 256 * 256;
+        b.temb = reinterpret_cast<float*>(w); w += ((size_t)m->temb_dim * B * 4 + 255) / 256 * 256;
+        b.ss = reinterpret_cast<float*>(w); w += ((size_t)m->ss_floats_per_sample * B * 4 + 255) / 256 * 256;
+        b.ss_lin = reinterpret_cast<float*>(w); w += ((size_t)m->ss_floats_per_sample * B * 4 + 255) / 256 * 256;
+        b.stats = reinterpret_cast<double*>(w);
+    }
+    {   // backward workspace carve
+        float* w = reinterpret_cast<float*>(bwd_workspace);
+        b.lv.resize(nl);
+        for (int l = 0; l < nl; ++l) {
+            const long s = c.image_size >> l;
+            const size_t n = al((size_t)B * c.num_frames * s * s * std::max<size_t>(lvl_width(m, l), m->init_dim));
+            b.lv[l].ga = w; w += n; b.lv[l].gb = w; w += n; b.lv[l].t1 = w; w += n; b.lv[l].t2 = w; w += n; b.lv[l].t3 = w; w += n; b.lv[l].gskip = w; w += n;
+        }
+        const size_t pix0 = (size_t)B * c.num_frames * c.image_size * c.image_size;
+        b.gr = w; w += al(pix0 * m->init_dim);
+        b.S = w; w += al(pix0 * (size_t)(c.attn_heads * 32) * 8);
+        b.dss = w; w += al((size_t)m->ss_floats_per_sample * B);
+        b.dtemb = w; w += al((size_t)m->temb_dim * B);
+        b.normscr = w; w += al((size_t)B * (2 * 1024 + 64));
+        b.sla_a = w;
+    }
+    hipError_t e;
+#define VDX_E(x) do { e = (x); if (e != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); } while (0)
+    const long pix0 = b.pix(0) * B;
+    float* g = state->g;
+    for (int stage = stage_hi; stage >= stage_lo; --stage) {
+        if (stage == top) {
+            // fresh pass: zero every accumulator
+            VDX_E(hipMemsetAsync(grads, 0, (size_t)m->param_total * 4, st));
+            VDX_E(hipMemsetAsync(b.dss, 0, (size_t)m->ss_floats_per_sample * B * 4, st));
+            VDX_E(hipMemsetAsync(b.dtemb, 0, (size_t)m->temb_dim * B * 4, st));
+            // head: out = conv1x1(fin(concat(x_up, r)))
+            const Level& U = m->ups[nl - 1];
+            VDX_E(launch_final_conv_bwd(b.slot(m->fin.s_out), d_out, params + m->fin_w, b.lv[0].ga, grads + m->fin_w, grads + m->fin_b, pix0, c.dim, m->out_dim, st));
+            res_bwd(b, m->fin, b.lv[0].ga, b.slot(U.s_attn), U.cout, b.slot(m->s_init_attn), m->init_dim, 0, b.lv[0].gb, b.gr);
+            g = b.lv[0].gb;
+        } else if (stage >= nl + 2) {
+            const int i = stage - (nl + 2);
+            const Level& L = m->ups[i];
+            const Level& D = m->downs[nl - 1 - i];
+            const int lvl = L.lvl;
+            LevelBufs& LB = b.lv[lvl];
+            if (L.has_resample) {                                  // g is at level lvl-1: Upsample backward
+                wgrad(b, b.slot(L.s_attn), L.cout, nullptr, 0, g, L.cout, L.rs_w, lvl, 1, 4, 1);
+                colsum(b, g, b.pix(lvl - 1) * B, L.cout, L.rs_b);
+                dgrad(b, g, L.cout, b.pt + L.pt_rs, L.cout, 0, L.cout, lvl, 1, 4, 1, nullptr, LB.ga);
+                g = LB.ga;
+            }
+            const float* attn_in = L.has_sla ? b.slot(L.s_sla) : b.slot(L.res1.s_out);
+            float* o = other(LB, g);
+            attn_bwd(b, L.attn, g, attn_in, lvl, true, o); g = o;
+            if (L.has_sla) { o = other(LB, g); sla_bwd(b, L.sla, g, b.slot(L.res1.s_out), lvl, o); g = o; }
+            o = other(LB, g);
+            res_bwd(b, L.res1, g, b.slot(L.res0.s_out), L.cout, nullptr, 0, lvl, o, nullptr); g = o;
+            const float* xin = (i == 0) ? b.slot(m->mid2.s_out) : b.slot(m->ups[i - 1].s_rs);
+            const int cx = (i == 0) ? m->mid2.cout : m->ups[i - 1].cout;
+            o = other(LB, g);
+            res_bwd(b, L.res0, g, xin, cx, b.slot(D.s_attn), D.cout, lvl, o, LB.gskip); g = o;
+        } else if (stage == nl + 1) {
+            const int lvl = nl - 1;
+            LevelBufs& LB = b.lv[lvl];
+            float* o = other(LB, g);
+            res_bwd(b, m->mid2, g, b.slot(m->s_mid_tattn), m->mid2.cin, nullptr, 0, lvl, o, nullptr); g = o;
+            o = other(LB, g); attn_bwd(b, m->mid_tattn, g, b.slot(m->s_mid_sattn), lvl, true, o); g = o;
+            o = other(LB, g); attn_bwd(b, m->mid_sattn, g, b.slot(m->mid1.s_out), lvl, false, o); g = o;
+            const Level& D = m->downs[nl - 1];
+            o = other(LB, g);
+            res_bwd(b, m->mid1, g, b.slot(D.s_attn), D.cout, nullptr, 0, lvl, o, nullptr); g = o;
+        } else if (stage >= 1) {
+            const int i = stage - 1;
+            const Level& L = m->downs[i];
+            LevelBufs& LB = b.lv[i];
+            if (L.has_resample) {                                  // g is at level i+1: Downsample backward
+                wgrad(b, b.slot(L.s_attn), L.cout, nullptr, 0, g, L.cout, L.rs_w, i, 0, 4, 2);
+                colsum(b, g, b.pix(i + 1) * B, L.cout, L.rs_b);
+                dgrad(b, g, L.cout, b.pt + L.pt_rs, L.cout, 0, L.cout, i, 0, 4, 2, LB.gskip, LB.ga);      // + skip gradient
+                g = LB.ga;
+            } else {
+                VDX_E(launch_add_inplace(g, LB.gskip, b.pix(i) * B * L.cout, st));
+            }
+            const float* attn_in = L.has_sla ? b.slot(L.s_sla) : b.slot(L.res1.s_out);
+            float* o = other(LB, g);
+            attn_bwd(b, L.attn, g, attn_in, i, true, o); g = o;
+            if (L.has_sla) { o = other(LB, g); sla_bwd(b, L.sla, g, b.slot(L.res1.s_out), i, o); g = o; }
+            o = other(LB, g);
+            res_bwd(b, L.res1, g, b.slot(L.res0.s_out), L.cout, nullptr, 0, i, o, nullptr); g = o;
+            const float* xin = (i == 0) ? b.slot(m->s_init_attn) : b.slot(m->downs[i - 1].s_rs);
+            o = other(LB, g);
+            res_bwd(b, L.res0, g, xin, L.cin, nullptr, 0, i, o, nullptr); g = o;
+        } else {
+            // stem: r gradient joins, init temporal attention, init conv, time-embedding MLPs
+            LevelBufs& LB = b.lv[0];
+            VDX_E(launch_add_inplace(g, b.gr, pix0 * m->init_dim, st));
+            float* o = other(LB, g);
+            attn_bwd(b, m->init_attn, g, b.slot(m->s_init), 0, true, o); g = o;
+            VDX_E(launch_init_conv_wgrad(x, g, grads + m->init_w, grads + m->init_b, B, c.channels, c.num_frames, c.image_size, c.image_size,
+                                         m->init_dim, c.init_kernel_size, st));
+            VDX_E(launch_resblock_ss_bwd(params, grads, b.temb, m->d_ss_layers, (int)m->ss_layers.size(), b.ss_lin, b.dss, b.dtemb, m->temb_dim, B, st));
+            TimeMlpArgs t;
+            memset(&t, 0, sizeof(t));
+            t.time = time; t.w1 = params + m->t_w1; t.b1 = params + m->t_b1; t.w2 = params + m->t_w2; t.b2 = params + m->t_b2;
+            t.dim = c.dim; t.time_dim = m->time_dim; t.cond = cond; t.cond_mask = cond_mask; t.null_all = null_all; t.cond_dim = c.cond_dim; t.temb_dim = m->temb_dim;
+            VDX_E(launch_time_mlp_bwd(t, b.dtemb, grads + m->t_w1, grads + m->t_b1, grads + m->t_w2, grads + m->t_b2,
+                                      c.cond_dim ? grads + m->null_cond : nullptr, B, st));
+        }
+        if (b.err != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(b.err), __FILE__, __LINE__);
+    }
+#undef VDX_E
+    state->g = g;
+    state->next_stage = stage_lo - 1;
+    return VDX_OK;
+}
+
+}  // namespace vdx

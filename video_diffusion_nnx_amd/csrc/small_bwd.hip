@@ -1,0 +1,239 @@
+// Small backward kernels (gfx950): final 1x1 conv, init 7x7 conv weight gradient, time-embedding MLPs.
+// Autodiff of unet3d.py:110-115,128-133,251,288-298 and modules.py:202-208,233-238 (reference trainer.py:361).
+#include "vdx_common.h"
+#include "vdx_internal.h"
+
+namespace vdx {
+
+// final conv: dx[pix][c] = sum_co dout[pix][co] W[c][co]
+__global__ __launch_bounds__(256) void final_conv_dx_kernel(const float* __restrict__ dout, const float* __restrict__ w, float* __restrict__ dx,
+                                                            long npix, int D, int Cout) {
+    const long n4 = npix * (D / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / (D / 4);
+        const int c = (int)(i % (D / 4)) * 4;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int co = 0; co < Cout; ++co) {
+            const float d = dout[pix * Cout + co];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = fmaf(d, w[(size_t)(c + e) * Cout + co], o[e]);
+        }
+        *reinterpret_cast<float4*>(dx + pix * D + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// final conv: dW[c][co] += sum_pix x[pix][c] dout[pix][co] ; db[co] += sum_pix dout[pix][co]     (D <= 256, Cout <= 4)
+__global__ __launch_bounds__(256) void final_conv_dw_kernel(const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dW,
+                                                            float* __restrict__ db, long npix, int D, int Cout) {
+    __shared__ float red[256 * 4];
+    const int c = threadIdx.x % D, pl = threadIdx.x / D, PL = 256 / D;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pl < PL)
+        for (long pix = (long)blockIdx.x * PL + pl; pix < npix; pix += (long)gridDim.x * PL) {
+            const float xv = x[pix * D + c];
+            for (int co = 0; co < Cout; ++co) { const float d = dout[pix * Cout + co]; acc[co] = fmaf(xv, d, acc[co]); accb[co] += d; }
+        }
+    for (int co = 0; co < Cout; ++co) {
+        __syncthreads();
+        red[threadIdx.x] = (pl < PL) ? acc[co] : 0.f;
+        __syncthreads();
+        if (pl == 0) {
+            float t = 0.f;
+            for (int k = 0; k < PL; ++k) t += red[k * D + c];
+            atomicAdd(dW + (size_t)c * Cout + co, t);
+        }
+        if (c == 0 && pl < PL) atomicAdd(db + co, accb[co]);
+    }
+}
+
+// init conv weight gradient: x external [B,Cin,F,H,W]; dy channel-last [B,F,H,W,Cout]; dW Flax (K,K,Cin,Cout); db [Cout]
+__global__ __launch_bounds__(256) void init_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dW,
+                                                              float* __restrict__ db, int B, int Cin, int F, int H, int W, int Cout, int K) {
+    extern __shared__ float sm[];
+    const int pad = K / 2, TW = 16 + K - 1;
+    float* xs = sm;                               // [Cin][TW][TW]
+    float* ds = sm + Cin * TW * TW;               // [256][17]
+    const int tx = blockIdx.x % ((W + 15) / 16), ty = blockIdx.x / ((W + 15) / 16);
+    const int f = blockIdx.y % F, b = blockIdx.y / F;
+    const int co0 = blockIdx.z * 16;
+    for (int i = threadIdx.x; i < Cin * TW * TW; i += 256) {
+        const int c = i / (TW * TW), r = i % (TW * TW);
+        const int gy = ty * 16 + r / TW - pad, gx = tx * 16 + r % TW - pad;
+        xs[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((((size_t)b * Cin + c) * F + f) * H + gy) * W + gx] : 0.f;
+    }
+    for (int i = threadIdx.x; i < 256 * 16; i += 256) {
+        const int p = i >> 4, j = i & 15;
+        const int oy = ty * 16 + (p >> 4), ox = tx * 16 + (p & 15);
+        ds[p * 17 + j] = (oy < H && ox < W && co0 + j < Cout) ? dy[((((size_t)b * F + f) * H + oy) * W + ox) * Cout + co0 + j] : 0.f;
+    }
+    __syncthreads();
+    const int nout = K * K * Cin * 16;
+    for (int o = threadIdx.x; o < nout; o += 256) {
+        const int j = o & 15, r = o >> 4;
+        const int c = r % Cin, tap = r / Cin;
+        const int ky = tap / K, kx = tap % K;
+        float acc = 0.f;
+        for (int p = 0; p < 256; ++p) acc = fmaf(xs[(c * TW + (p >> 4) + ky) * TW + (p & 15) + kx], ds[p * 17 + j], acc);
+        if (co0 + j < Cout) atomicAdd(dW + ((size_t)tap * Cin + c) * Cout + co0 + j, acc);
+    }
+    if (threadIdx.x < 16 && co0 + threadIdx.x < Cout) {
+        float t = 0.f;
+        for (int p = 0; p < 256; ++p) t += ds[p * 17 + threadIdx.x];
+        atomicAdd(db + co0 + threadIdx.x, t);
+    }
+}
+
+__device__ __forceinline__ float dsilu2_f(float z) {
+    const float sg = 1.0f / (1.0f + __expf(-z));
+    return sg * (1.0f + z * (1.0f - sg));
+}
+
+// per-ResnetBlock time MLP backward.  grid = nlayers.  dss (in: d(scale|shift), overwritten by d(lin)) laid out like ss.
+// lin = the forward's pre-LayerNorm values.  dtemb [B][temb_dim] accumulated (atomics across layers).
+__global__ __launch_bounds__(256) void resblock_ss_bwd_kernel(const float* __restrict__ params, float* __restrict__ grads, const float* __restrict__ temb,
+                                                              const SsLayer* __restrict__ layers, const float* __restrict__ lin_base,
+                                                              float* __restrict__ dss_base, float* __restrict__ dtemb, int temb_dim, int B) {
+    extern __shared__ float sm[];                  // act[B][temb_dim] | red[16]
+    float* act = sm;
+    float* red = sm + (size_t)B * temb_dim;
+    const int tid = threadIdx.x;
+    const SsLayer L = layers[blockIdx.x];
+    const int N = L.n;
+    for (int i = tid; i < B * temb_dim; i += 256) act[i] = silu_f(temb[i]);
+    const float* W = params + L.w_off;
+    const float* g = params + L.g_off;
+    float* dW = grads + L.w_off; float* db = grads + L.b_off; float* dg = grads + L.g_off; float* dbe = grads + L.be_off;
+    const float* lin = lin_base + (size_t)L.out_off * B;
+    float* dss = dss_base + (size_t)L.out_off * B;
+    // LayerNorm backward per sample (in place: dss <- dlin), parameter gradients accumulated over samples
+    for (int b = 0; b < B; ++b) {
+        float s = 0.f, ss = 0.f;
+        for (int n = tid; n < N; n += 256) { const float v = lin[(size_t)b * N + n]; s += v; ss += v * v; }
+        for (int o = 1; o < 64; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+        __syncthreads();
+        if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = ss; }
+        __syncthreads();
+        s = red[0] + red[1] + red[2] + red[3]; ss = red[4] + red[5] + red[6] + red[7];
+        const float mean = s / N, rstd = rsqrtf(fmaxf(ss / N - mean * mean, 0.f) + NORM_EPS);
+        float m1 = 0.f, m2 = 0.f;
+        for (int n = tid; n < N; n += 256) {
+            const float xh = (lin[(size_t)b * N + n] - mean) * rstd, d = dss[(size_t)b * N + n], gd = g[n] * d;
+            m1 += gd; m2 += gd * xh;
+            dg[n] += d * xh; dbe[n] += d;                       // this workgroup owns the layer's parameters: no atomics
+        }
+        for (int o = 1; o < 64; o <<= 1) { m1 += __shfl_xor(m1, o); m2 += __shfl_xor(m2, o); }
+        __syncthreads();
+        if ((tid & 63) == 0) { red[8 + (tid >> 6)] = m1; red[12 + (tid >> 6)] = m2; }
+        __syncthreads();
+        m1 = (red[8] + red[9] + red[10] + red[11]) / N; m2 = (red[12] + red[13] + red[14] + red[15]) / N;
+        for (int n = tid; n < N; n += 256) {
+            const float xh = (lin[(size_t)b * N + n] - mean) * rstd;
+            const float dl = rstd * (g[n] * dss[(size_t)b * N + n] - m1 - xh * m2);
+            dss[(size_t)b * N + n] = dl;
+            db[n] += dl;
+        }
+        __syncthreads();
+    }
+    // dW[k][n] += sum_b act[b][k] dlin[b][n]
+    for (int n = tid; n < N; n += 256)
+        for (int k = 0; k < temb_dim; ++k) {
+            float acc = 0.f;
+            for (int b = 0; b < B; ++b) acc = fmaf(act[(size_t)b * temb_dim + k], dss[(size_t)b * N + n], acc);
+            dW[(size_t)k * N + n] += acc;
+        }
+    // dtemb[b][k] += silu'(temb) * sum_n dlin[b][n] W[k][n]
+    for (int k = tid; k < temb_dim; k += 256)
+        for (int b = 0; b < B; ++b) {
+            float acc = 0.f;
+            for (int n = 0; n < N; ++n) acc = fmaf(dss[(size_t)b * N + n], W[(size_t)k * N + n], acc);
+            atomicAdd(dtemb + (size_t)b * temb_dim + k, acc * dsilu2_f(temb[(size_t)b * temb_dim + k]));
+        }
+}
+
+__device__ __forceinline__ float gelu_tanh_b(float x) {
+    return 0.5f * x * (1.0f + tanhf(0.7978845608028654f * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float dgelu_tanh_b(float x) {
+    const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+    const float t = tanhf(u);
+    return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
+}
+
+// time MLP backward, single workgroup (tiny): recomputes emb / lin1 / h per sample
+__global__ __launch_bounds__(256) void time_mlp_bwd_kernel(TimeMlpArgs P, const float* __restrict__ dtemb, float* __restrict__ dw1, float* __restrict__ db1,
+                                                           float* __restrict__ dw2, float* __restrict__ db2, float* __restrict__ dnull, int B) {
+    extern __shared__ float sm[];                  // emb[dim] | lin1[td] | h[td] | dlin1[td]
+    float* emb = sm; float* lin1 = emb + P.dim; float* h = lin1 + P.time_dim; float* dl1 = h + P.time_dim;
+    const int tid = threadIdx.x, half = P.dim / 2, td = P.time_dim;
+    for (int b = 0; b < B; ++b) {
+        __syncthreads();
+        const float tval = (float)P.time[b];
+        for (int i = tid; i < half; i += 256) {
+            const float fr = expf((float)i * -(logf(10000.0f) / (float)(half - 1)));
+            emb[i] = sinf(tval * fr); emb[half + i] = cosf(tval * fr);
+        }
+        __syncthreads();
+        for (int n = tid; n < td; n += 256) {
+            float acc = P.b1[n];
+            for (int k = 0; k < P.dim; ++k) acc = fmaf(emb[k], P.w1[(size_t)k * td + n], acc);
+            lin1[n] = acc; h[n] = gelu_tanh_b(acc);
+        }
+        __syncthreads();
+        const float* dt = dtemb + (size_t)b * P.temb_dim;
+        for (int n = tid; n < td; n += 256) {
+            db2[n] += dt[n];
+            for (int k = 0; k < td; ++k) dw2[(size_t)k * td + n] += h[k] * dt[n];
+        }
+        for (int k = tid; k < td; k += 256) {
+            float acc = 0.f;
+            for (int n = 0; n < td; ++n) acc = fmaf(dt[n], P.w2[(size_t)k * td + n], acc);
+            dl1[k] = acc * dgelu_tanh_b(lin1[k]);
+        }
+        __syncthreads();
+        for (int k = tid; k < td; k += 256) {
+            db1[k] += dl1[k];
+            for (int j = 0; j < P.dim; ++j) dw1[(size_t)j * td + k] += emb[j] * dl1[k];
+        }
+        if (P.cond_dim && dnull) {
+            const bool use_null = P.cond_mask ? (P.cond_mask[b] != 0) : (P.null_all != 0);
+            if (use_null) for (int n = tid; n < P.cond_dim; n += 256) dnull[n] += dt[td + n];
+        }
+    }
+}
+
+hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, hipStream_t st) {
+    if (D > 256 || Cout > 4) return hipErrorInvalidValue;
+    const int blocks = (int)std::max<long>(1, std::min<long>((npix * (D / 4) + 255) / 256, 4096));
+    hipLaunchKernelGGL(final_conv_dx_kernel, dim3(blocks), dim3(256), 0, st, dout, w, dx, npix, D, Cout);
+    const int PL = 256 / D;
+    const int b2 = (int)std::max<long>(1, std::min<long>((npix + PL - 1) / PL, 512));
+    hipLaunchKernelGGL(final_conv_dw_kernel, dim3(b2), dim3(256), 0, st, x, dout, dW, db, npix, D, Cout);
+    return hipGetLastError();
+}
+
+hipError_t launch_init_conv_wgrad(const float* x, const float* dy, float* dW, float* db, int B, int Cin, int F, int H, int W, int Cout, int K, hipStream_t st) {
+    const int TW = 16 + K - 1;
+    dim3 grid(((W + 15) / 16) * ((H + 15) / 16), B * F, (Cout + 15) / 16);
+    const size_t lds = ((size_t)Cin * TW * TW + 256 * 17) * 4;
+    hipLaunchKernelGGL(init_conv_wgrad_kernel, grid, dim3(256), lds, st, x, dy, dW, db, B, Cin, F, H, W, Cout, K);
+    return hipGetLastError();
+}
+
+hipError_t launch_resblock_ss_bwd(const float* params, float* grads, const float* temb, const SsLayer* layers, int nlayers, const float* lin_base,
+                                  float* dss_base, float* dtemb, int temb_dim, int B, hipStream_t st) {
+    const size_t lds = ((size_t)B * temb_dim + 16) * 4;
+    auto kfn = resblock_ss_bwd_kernel;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3(nlayers), dim3(256), lds, st, params, grads, temb, layers, lin_base, dss_base, dtemb, temb_dim, B);
+    return hipGetLastError();
+}
+
+hipError_t launch_time_mlp_bwd(const TimeMlpArgs& a, const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, float* dnull, int B, hipStream_t st) {
+    hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3(1), dim3(256), (size_t)(a.dim + 3 * a.time_dim) * 4, st, a, dtemb, dw1, db1, dw2, db2, dnull, B);
+    return hipGetLastError();
+}
+
+}  // namespace vdx

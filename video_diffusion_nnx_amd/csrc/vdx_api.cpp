@@ -10,6 +10,7 @@ struct vdx_handle {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     struct GraphKey { const void* p[8]; unsigned long long seed; int i[4]; size_t ws; } graph_key;
+    vdx::BwdState bwd;
 };
 
 static thread_local char g_err[512] = "";
@@ -394,6 +395,25 @@ int vdx_colsum(const float* x, float* out, long rows, int c, void* stream) {
     if (!x || !out || rows < 0 || c < 1 || c % 4) VDX_FAIL(VDX_ERR_INVALID, "colsum: bad argument");
     if (rows) VDX_HIP(vdx::launch_colsum(x, out, rows, c, (hipStream_t)stream));
     return VDX_OK;
+}
+
+int vdx_num_stages(const vdx_handle* h) { return h ? 2 * h->model.cfg.n_mults + 3 : 0; }
+size_t vdx_packed_bwd_bytes(const vdx_handle* h) { return h ? h->model.packed_t_bytes : 0; }
+size_t vdx_bwd_workspace_bytes(const vdx_handle* h, int batch) { return h ? vdx::model_bwd_workspace_bytes(&h->model, batch) : 0; }
+
+int vdx_pack_params_bwd(const vdx_handle* h, const float* params, void* packed_t, void* stream) {
+    if (!h || !params || !packed_t) VDX_FAIL(VDX_ERR_INVALID, "pack_params_bwd: null argument");
+    VDX_HIP(vdx::model_pack_t(&h->model, params, packed_t, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_unet_backward(vdx_handle* h, const float* params, const void* packed, const void* packed_t, const float* x, const int* time,
+                      const float* cond, const unsigned char* cond_mask, int null_all, const float* d_out, void* fwd_workspace,
+                      void* bwd_workspace, size_t bwd_workspace_bytes, float* grads, int stage_hi, int stage_lo, int batch, void* stream) {
+    if (!h || !params || !packed || !packed_t || !x || !time || !d_out || !fwd_workspace || !bwd_workspace || !grads) VDX_FAIL(VDX_ERR_INVALID, "unet_backward: null argument");
+    if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "unet_backward: handle was created without a GPU");
+    return vdx::model_backward(&h->model, &h->bwd, params, packed, packed_t, x, time, cond, cond_mask, null_all, d_out, fwd_workspace,
+                               bwd_workspace, bwd_workspace_bytes, grads, stage_hi, stage_lo, batch, (hipStream_t)stream);
 }
 
 int vdx_loss_grad(const float* eps_hat, const float* noise, float* d_eps_hat, int batch, int channels, long fhw, int l2, void* stream) {

@@ -60,7 +60,7 @@ hipError_t launch_init_conv(const float* x, const float* w, const float* bias, f
 hipError_t launch_final_conv(const float* x, const float* w, const float* bias, float* y, long npix, int D, int Cout, hipStream_t st);
 hipError_t launch_time_mlp(const TimeMlpArgs& a, int B, hipStream_t st);
 hipError_t launch_resblock_ss(const float* params, const float* temb, const SsLayer* layers, int nlayers, float* ss_base,
-                              int temb_dim, int B, hipStream_t st);
+                              float* lin_base, int temb_dim, int B, hipStream_t st);
 
 // y = MHA(x) + x over sequences of L tokens; token address = (s / inner) * outer_stride + (s % inner) * inner_stride + tok * tok_stride
 struct AttnArgs {
@@ -150,6 +150,12 @@ struct SlaBwdArgs {
 };
 size_t sla_bwd_scratch_floats(int NF, int heads);
 hipError_t launch_sla_bwd(const SlaBwdArgs& a, hipStream_t st);
+
+hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, hipStream_t st);
+hipError_t launch_init_conv_wgrad(const float* x, const float* dy, float* dW, float* db, int B, int Cin, int F, int H, int W, int Cout, int K, hipStream_t st);
+hipError_t launch_resblock_ss_bwd(const float* params, float* grads, const float* temb, const SsLayer* layers, int nlayers, const float* lin_base,
+                                  float* dss_base, float* dtemb, int temb_dim, int B, hipStream_t st);
+hipError_t launch_time_mlp_bwd(const TimeMlpArgs& a, const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, float* dnull, int B, hipStream_t st);
 
 size_t conv_packed_bytes(int mode, int taps, int Cin, int Cout);
 int conv_cin_pad(int mode, int Cin);

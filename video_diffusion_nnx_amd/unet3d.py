@@ -56,6 +56,11 @@ vdx_pack_params = L._sig('vdx_pack_params', C.c_int, [_vp, _vp, _vp, _vp])
 vdx_workspace_bytes = L._sig('vdx_workspace_bytes', C.c_size_t, [_vp, C.c_int])
 vdx_slot_count = L._sig('vdx_slot_count', C.c_int, [_vp])
 vdx_slot_info = L._sig('vdx_slot_info', C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)])
+vdx_num_stages = L._sig('vdx_num_stages', C.c_int, [_vp])
+vdx_packed_bwd_bytes = L._sig('vdx_packed_bwd_bytes', C.c_size_t, [_vp])
+vdx_pack_params_bwd = L._sig('vdx_pack_params_bwd', C.c_int, [_vp, _vp, _vp, _vp])
+vdx_bwd_workspace_bytes = L._sig('vdx_bwd_workspace_bytes', C.c_size_t, [_vp, C.c_int])
+vdx_unet_backward = L._sig('vdx_unet_backward', C.c_int, [_vp] * 7 + [_vp, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, C.c_int, C.c_int, C.c_int, _vp])
 vdx_unet_forward = L._sig('vdx_unet_forward', C.c_int, [_vp] * 7 + [C.c_int, _vp, _vp, C.c_size_t, C.c_int, _vp])
 
 
@@ -131,6 +136,10 @@ class Unet3D:
         self._ws: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self._packed: Optional[torch.Tensor] = None
         self._packed_version = -1
+        self._packed_t: Optional[torch.Tensor] = None
+        self._packed_t_version = -1
+        self._bws: Dict[Tuple[int, int, int], torch.Tensor] = {}
+        self._last_fwd = None
         self._param_version = 0
         # layout comes from the C++ runtime; geometry does not affect it
         self._layout_handle = self._make_handle(frames=1, size=2 ** (len(self.dim_mults) - 1))
@@ -245,6 +254,39 @@ class Unet3D:
             self._packed_version = self._param_version
         return self._packed
 
+    def packed_t(self) -> torch.Tensor:
+        """Transposed packing used by the backward's data gradients; re-packed lazily after parameter updates."""
+        self._require_gpu()
+        if self._packed_t is None:
+            self._packed_t = torch.empty(vdx_packed_bwd_bytes(self._layout_handle.ptr), dtype=torch.uint8, device=self.device)
+        if self._packed_t_version != self._param_version:
+            L.check(vdx_pack_params_bwd(self._layout_handle.ptr, L.ptr(self.flat_params), L.ptr(self._packed_t), L.stream_ptr()))
+            self._packed_t_version = self._param_version
+        return self._packed_t
+
+    def bwd_workspace(self, batch: int, frames: int, size: int) -> torch.Tensor:
+        key = (batch, frames, size)
+        if key not in self._bws:
+            self._bws[key] = torch.empty(vdx_bwd_workspace_bytes(self.handle(frames, size).ptr, batch), dtype=torch.uint8, device=self.device)
+        return self._bws[key]
+
+    @property
+    def num_stages(self) -> int:
+        return vdx_num_stages(self._layout_handle.ptr)
+
+    def backward(self, d_out: torch.Tensor, grads: torch.Tensor, stage_hi: Optional[int] = None, stage_lo: int = 0) -> None:
+        """Reverse pass of the LAST __call__ (same inputs, same workspace): accumulates dL/dparams into the flat `grads`
+        (zeroed by the head stage).  d_out = dL/d(output) [B,F,H,W,out_dim].  Stages descend from num_stages-1 to 0."""
+        assert self._last_fwd is not None, 'backward() needs a preceding forward'
+        x, t32, cond, cm, null_all, B, Fr, S = self._last_fwd
+        if stage_hi is None:
+            stage_hi = self.num_stages - 1
+        h = self.handle(Fr, S)
+        ws, bws = self.workspace(B, Fr, S), self.bwd_workspace(B, Fr, S)
+        L.check(vdx_unet_backward(h.ptr, L.ptr(self.flat_params), L.ptr(self.packed()), L.ptr(self.packed_t()), L.ptr(x), L.ptr(t32),
+                                  L.ptr(cond) if self.has_cond else 0, L.ptr(cm), null_all, L.ptr(d_out), L.ptr(ws), L.ptr(bws), bws.numel(),
+                                  L.ptr(grads), stage_hi, stage_lo, B, L.stream_ptr()))
+
     def workspace(self, batch: int, frames: int, size: int) -> torch.Tensor:
         key = (batch, frames, size)
         if key not in self._ws:
@@ -295,6 +337,7 @@ class Unet3D:
         L.check(vdx_unet_forward(h.ptr, L.ptr(self.flat_params), L.ptr(self.packed()), L.ptr(x), L.ptr(t32),
                                  L.ptr(cond) if self.has_cond else 0, L.ptr(cm), null_all, L.ptr(out), L.ptr(ws), ws.numel(), B,
                                  L.stream_ptr()))
+        self._last_fwd = (x, t32, cond if self.has_cond else None, cm, null_all, B, Fr, H)     # inputs kept alive for backward()
         return out
 
     def forward_with_cond_scale(self, *args, cond_scale=2.0, **kwargs):
