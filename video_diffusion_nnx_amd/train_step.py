@@ -34,4 +34,42 @@ def stage_of_param(name: str, n_levels: int) -> int:
 
 
 def run_train_step(tr, batch: torch.Tensor, step: int) -> torch.Tensor:
-    raise NotImplementedError('the HIP backward (vdx_unet_backward) lands next; see DESIGN.md §6')
+    """loss, grads = value_and_grad(p_losses); Adam; EMA  (trainer.py:337-382) for this rank's shard of the batch."""
+    from .trainer import GradBucketReducer
+    gd, unet = tr.model, tr.unet
+    dev = tr.device
+    x = torch.as_tensor(batch).to(dev, torch.float32).contiguous()
+    B = x.shape[0]
+    assert tuple(x.shape[1:]) == (gd.channels, gd.num_frames, gd.image_size, gd.image_size), \
+        f'expected [b, {gd.channels}, {gd.num_frames}, {gd.image_size}, {gd.image_size}], got {tuple(x.shape)}'     # check_shape (:490)
+    # keys: one stream per (seed, rank), split per step like `key, step_key = split(key)` (trainer.py:541)
+    step_key = split_key(split_key(tr.rng_seed, tr.rank + 1)[-1], step + 1)[-1]
+    _, t_key, loss_key = split_key(step_key, 3)
+    _, noise_key, _ = split_key(loss_key, 3)
+    g = torch.Generator().manual_seed(t_key & 0x7FFFFFFFFFFFFFFF)
+    t = torch.randint(0, gd.num_timesteps, (B,), generator=g, dtype=torch.int32).to(dev)
+    noise = gd.randn(x.shape, noise_key, 0)
+    tr.last_t, tr.last_noise_key = t, noise_key
+    x_noisy = gd.q_sample(x, t, noise=noise, _pre=(2.0, -1.0))                    # normalize_img folded in (:499)
+    eps_hat = unet(x_noisy, t)
+    acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    fhw = x.numel() // (B * gd.channels)
+    l2 = int(gd.loss_type == 'l2')
+    L.check(vdx_loss_sum(L.ptr(eps_hat), L.ptr(noise), L.ptr(acc), B, gd.channels, fhw, l2, L.stream_ptr()))
+    loss = (acc / float(x.numel())).to(torch.float32).reshape(())
+    d_eps = torch.empty_like(eps_hat)
+    L.check(vdx_loss_grad(L.ptr(eps_hat), L.ptr(noise), L.ptr(d_eps), B, gd.channels, fhw, l2, L.stream_ptr()))
+    # reverse pass stage by stage; finished gradient buckets are all-reduced (RCCL) while earlier stages still run
+    reducer = GradBucketReducer(tr.grads, tr.buckets)
+    ns = unet.num_stages
+    for stage in range(ns - 1, -1, -1):
+        unet.backward(d_eps, tr.grads, stage, stage)
+        reducer.stage_done(stage)
+    reducer.finish()
+    lr = tr.current_lr(tr.opt_count)                                               # schedule at the pre-increment count (B.2)
+    do_ema = int(step >= tr.step_start_ema and step % tr.update_ema_every == 0)    # trainer.py:373-374
+    L.check(vdx_adam_ema_step(L.ptr(unet.flat_params), L.ptr(tr.grads), L.ptr(tr.m), L.ptr(tr.v), L.ptr(tr.ema), unet.flat_params.numel(),
+                              lr, 0.9, 0.999, 1e-8, tr.opt_count, 1.0 / reducer.world, do_ema, tr.ema_decay, L.stream_ptr()))
+    tr.opt_count += 1
+    unet.mark_params_updated()
+    return loss

@@ -125,6 +125,9 @@ class Trainer:
         self.ema = self.unet.flat_params.clone()
         self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
         self.opt_count = 0                                       # optax count: restarts at 0 on resume
+        from .train_step import stage_of_param
+        nlev = len(self.unet.dim_mults)
+        self.buckets = make_buckets(self.unet.param_table, n, lambda nm: stage_of_param(nm, nlev), stage_of_param('__count__', nlev))
         # ---- dataset ----
         self.image_size = diffusion_model.image_size
         if str(dataset_path).startswith('synthetic'):
