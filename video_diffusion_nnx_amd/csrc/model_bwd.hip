@@ -46,11 +46,11 @@ void dgrad(Bwd& b, const float* dy, int Cdy, const void* wpt, int rows_total, in
     b.ok(launch_conv(b.m->mode, a, b.st));
 }
 
-void wgrad(Bwd& b, const float* x0, int c0, const float* x1, int c1, const float* dy, int Cout, long w_off, int lvl_in, int kind, int k, int stride,
+void wgrad(Bwd& b, const float* x0, int c0, const float* x1, int c1, const float* dy, int Cout, long w_off, long b_off, int lvl_in, int kind, int k, int stride,
            const double* in_stats = nullptr, const float* gamma = nullptr, const float* beta = nullptr, const float* ss = nullptr, int ss_stride = 0) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.x0 = x0; a.x1 = x1; a.C0 = c0; a.C1 = c1; a.dy = dy; a.Cout = Cout; a.dW = b.grads + w_off;
+    a.x0 = x0; a.x1 = x1; a.C0 = c0; a.C1 = c1; a.dy = dy; a.Cout = Cout; a.dW = b.grads + w_off; a.db = b_off >= 0 ? b.grads + b_off : nullptr;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl_in);
     a.kind = kind; a.kh = a.kw = kind ? 4 : k; a.stride = kind ? 1 : stride;
     if (in_stats) { a.pro = 1; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta; a.groups = b.m->cfg.resnet_groups; a.ss = ss; a.ss_stride = ss_stride; }
@@ -76,8 +76,7 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     b.ok(launch_norm_bwd(t, b.st));
     // 2. conv2: y2 = conv(SiLU(GN1(y1)*(1+s)+sh))
     const float* ssrow = r.has_mlp ? b.ss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
-    wgrad(b, b.slot(r.s_y1), r.cout, nullptr, 0, L.t1, r.cout, r.b2_w, lvl, 0, 3, 1, b.stat(r.st1), b.p + r.b1_gs, b.p + r.b1_gb, ssrow, 2 * r.cout);
-    colsum(b, L.t1, npix, r.cout, r.b2_b);
+    wgrad(b, b.slot(r.s_y1), r.cout, nullptr, 0, L.t1, r.cout, r.b2_w, r.b2_b, lvl, 0, 3, 1, b.stat(r.st1), b.p + r.b1_gs, b.p + r.b1_gb, ssrow, 2 * r.cout);
     dgrad(b, L.t1, r.cout, b.pt + r.pt_b2, r.cout, 0, r.cout, lvl, 0, 3, 1, nullptr, L.t3);            // dL/d(act1)
     // 3. prologue: act1 = SiLU((GN1(y1))*(1+s)+sh)
     NormBwdArgs q;
@@ -88,12 +87,10 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     q.R = b.normscr; q.G = b.normscr + (size_t)b.B * r.cout * 2; q.C = r.cout; q.batch = b.B; q.pix_per_sample = b.pix(lvl);
     b.ok(launch_norm_bwd(q, b.st));                                                                    // t1 = dL/d(y1)
     // 4. conv1 + residual branch
-    wgrad(b, x0, c0, x1, c1, L.t1, r.cout, r.b1_w, lvl, 0, 3, 1);
-    colsum(b, L.t1, npix, r.cout, r.b1_b);
+    wgrad(b, x0, c0, x1, c1, L.t1, r.cout, r.b1_w, r.b1_b, lvl, 0, 3, 1);
     const int cin = c0 + c1;
     if (r.has_res) {
-        wgrad(b, x0, c0, x1, c1, L.t2, r.cout, r.rc_w, lvl, 0, 1, 1);
-        colsum(b, L.t2, npix, r.cout, r.rc_b);
+        wgrad(b, x0, c0, x1, c1, L.t2, r.cout, r.rc_w, r.rc_b, lvl, 0, 1, 1);
         dgrad(b, L.t2, r.cout, b.pt + r.pt_rc, cin, 0, c0, lvl, 0, 1, 1, nullptr, L.t3);
         dgrad(b, L.t1, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t3, out0);
         if (c1) {
@@ -115,10 +112,10 @@ void proj(Bwd& b, const float* x, int cin, const void* wp, const float* bias, in
     b.ok(launch_conv(b.m->mode, a, b.st));
 }
 
-void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w_off, int lvl) {
+void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w_off, long b_off, int lvl) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.x0 = x; a.C0 = cin; a.dy = dy; a.Cout = cout; a.dW = b.grads + w_off;
+    a.x0 = x; a.C0 = cin; a.dy = dy; a.Cout = cout; a.dW = b.grads + w_off; a.db = b_off >= 0 ? b.grads + b_off : nullptr;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
     b.ok(launch_conv_wgrad(a, b.st));
@@ -140,10 +137,9 @@ void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, 
     if (temporal) { a.L = (int)Fr; a.nseq = b.B * hw; a.inner = hw; a.outer_p = Fr * hw; a.tok_p = hw; }
     else { a.L = (int)hw; a.nseq = b.B * Fr; a.inner = 1; a.outer_p = hw; a.tok_p = 1; }
     b.ok(launch_attn_core_bwd(a, b.st));
-    wgrad1x1(b, O, HD, g, C, ap.o_w, lvl);
-    colsum(b, g, npix, C, ap.o_b);
+    wgrad1x1(b, O, HD, g, C, ap.o_w, ap.o_b, lvl);
     float* d3[3] = {dq, dk, dv};
-    for (int i = 0; i < 3; ++i) { wgrad1x1(b, x, C, d3[i], HD, ap.w[i], lvl); colsum(b, d3[i], npix, HD, ap.b[i]); }
+    for (int i = 0; i < 3; ++i) wgrad1x1(b, x, C, d3[i], HD, ap.w[i], ap.b[i], lvl);
     proj(b, dq, HD, b.pt + ap.pt_w[0], nullptr, C, lvl, g, L.t1);
     proj(b, dk, HD, b.pt + ap.pt_w[1], nullptr, C, lvl, L.t1, L.t2);
     proj(b, dv, HD, b.pt + ap.pt_w[2], nullptr, C, lvl, L.t2, out);
@@ -165,9 +161,9 @@ void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, fl
     a.q = q; a.k = k; a.v = v; a.dOut = dOut; a.O = O; a.dq = dq; a.dk = dk; a.dv = dv; a.A = b.sla_a;
     a.NF = b.B * m->cfg.num_frames; a.N = b.size(lvl) * b.size(lvl); a.heads = m->cfg.attn_heads;
     b.ok(launch_sla_bwd(a, b.st));
-    wgrad1x1(b, O, HD, g, C, sp.o_w, lvl);
+    wgrad1x1(b, O, HD, g, C, sp.o_w, -1, lvl);
     float* d3[3] = {dq, dk, dv};
-    for (int i = 0; i < 3; ++i) wgrad1x1(b, x, C, d3[i], HD, sp.w[i], lvl);
+    for (int i = 0; i < 3; ++i) wgrad1x1(b, x, C, d3[i], HD, sp.w[i], -1, lvl);
     proj(b, dq, HD, b.pt + sp.pt_w[0], nullptr, C, lvl, g, L.t1);
     proj(b, dk, HD, b.pt + sp.pt_w[1], nullptr, C, lvl, L.t1, L.t2);
     proj(b, dv, HD, b.pt + sp.pt_w[2], nullptr, C, lvl, L.t2, out);
@@ -290,8 +286,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             const int lvl = L.lvl;
             LevelBufs& LB = b.lv[lvl];
             if (L.has_resample) {                                  // g is at level lvl-1: Upsample backward
-                wgrad(b, b.slot(L.s_attn), L.cout, nullptr, 0, g, L.cout, L.rs_w, lvl, 1, 4, 1);
-                colsum(b, g, b.pix(lvl - 1) * B, L.cout, L.rs_b);
+                wgrad(b, b.slot(L.s_attn), L.cout, nullptr, 0, g, L.cout, L.rs_w, L.rs_b, lvl, 1, 4, 1);
                 dgrad(b, g, L.cout, b.pt + L.pt_rs, L.cout, 0, L.cout, lvl, 1, 4, 1, nullptr, LB.ga);
                 g = LB.ga;
             }
@@ -320,8 +315,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             const Level& L = m->downs[i];
             LevelBufs& LB = b.lv[i];
             if (L.has_resample) {                                  // g is at level i+1: Downsample backward
-                wgrad(b, b.slot(L.s_attn), L.cout, nullptr, 0, g, L.cout, L.rs_w, i, 0, 4, 2);
-                colsum(b, g, b.pix(i + 1) * B, L.cout, L.rs_b);
+                wgrad(b, b.slot(L.s_attn), L.cout, nullptr, 0, g, L.cout, L.rs_w, L.rs_b, i, 0, 4, 2);
                 dgrad(b, g, L.cout, b.pt + L.pt_rs, L.cout, 0, L.cout, i, 0, 4, 2, LB.gskip, LB.ga);      // + skip gradient
                 g = LB.ga;
             } else {

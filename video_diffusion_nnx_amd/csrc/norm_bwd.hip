@@ -234,7 +234,8 @@ hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st) {
     a.lpp = lpp;
     const int vpl = (quads + lpp - 1) / lpp;
     const int ppb = 256 / lpp;
-    const int gx = (int)std::max<long>(1, std::min<long>((a.pix_per_sample + ppb - 1) / ppb, 512));
+    // few, fat workgroups: every workgroup ends in 2..4 atomics per channel onto the same [B][C] rows (contention-bound beyond ~64)
+    const int gx = (int)std::max<long>(1, std::min<long>((a.pix_per_sample + ppb - 1) / ppb, 48));
     hipError_t e = hipMemsetAsync(a.R, 0, (size_t)a.batch * a.C * 2 * 4, st);
     if (e != hipSuccess) return e;
     dim3 grid(gx, a.batch);

@@ -113,6 +113,7 @@ struct WgradArgs {
     const float* x0; const float* x1; int C0, C1;          // conv input (channel-last), optional concat
     const float* dy; int Cout;                             // output gradient [NF, Hy, Wy, Cout]
     float* dW;                                             // Flax layout [taps][Cin][Cout], accumulated with atomics
+    float* db;                                             // optional: db[co] += sum_pixels dY (bias gradient), or null
     int NF, F, H, W;                                       // input geometry
     int kind, kh, kw, stride;
     int pro; const double* in_stats; const float* gamma; const float* beta; int groups; const float* ss; int ss_stride;

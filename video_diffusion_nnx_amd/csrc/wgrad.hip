@@ -56,6 +56,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
     const int patches_per_frame = tiles_x * tiles_y;
     const long total_patches = (long)P.NF * patches_per_frame;
     int last_b = -1;
+    const bool do_bias = (blockIdx.y == 0) && (blockIdx.z / P.co_tiles == 0);
+    float bias_acc = 0.f;
     for (long pid = blockIdx.x; pid < total_patches; pid += gridDim.x) {
         const int f = (int)(pid / patches_per_frame);
         const int pr = (int)(pid % patches_per_frame);
@@ -117,6 +119,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
             *reinterpret_cast<float4*>(Bs + (size_t)bp * WG_LD + pc * 4) = v;
         }
         __syncthreads();
+        if (P.db && do_bias && tid < 64) {                     // column sums of this dY window (every dY pixel is staged exactly once per co tile)
+            float t = 0.f;
+            for (int bp = 0; bp < BPX; ++bp) t += Bs[(size_t)bp * WG_LD + tid];
+            bias_acc += t;
+        }
         // ---- K loop over the patch's "m" positions, 4 per MFMA step (positions beyond Hm/Wm hold zero dY) ----
         const int npos = P.PH * P.PW;
         for (int k0 = 0; k0 < npos; k0 += 4) {
@@ -135,6 +142,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
             }
         }
     }
+    if (P.db && do_bias && tid < 64 && co0 + tid < P.Cout) atomicAdd(P.db + co0 + tid, bias_acc);
     // ---- accumulate into dW (Flax layout [taps][Cin][Cout]) ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
