@@ -15,6 +15,7 @@
 // so q/k/v/scores never touch HBM: traffic = read x twice (GEMM1 + residual) + write y.
 #include "vdx_common.h"
 #include "vdx_internal.h"
+#include <stdlib.h>
 
 namespace vdx {
 
@@ -77,22 +78,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs P) {
         }
     };
     // per-head weight tile (96 rows x 128 B) prefetched through registers one K tile ahead
-    uint4 wpre[3];
+    // three named registers (an indexed array here ends up in scratch memory)
+    uint4 wp0 = make_uint4(0, 0, 0, 0), wp1 = wp0, wp2 = wp0;
+    const int wrow_ = tid >> 3, wpc_ = tid & 7;                       // piece j covers weight-tile row wrow_ + 32 j  (part j = q,k,v)
     auto wfetch = [&](int h, int kt) {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int i = tid + 256 * j;
-            const int row = i >> 3, pc = i & 7;
-            const int grow = (row >> 5) * HD + h * D + (row & 31);
-            wpre[j] = *reinterpret_cast<const uint4*>(wq + ((size_t)grow * P.CPad + (size_t)kt * KT) * M::ES + pc * 16);
-        }
+        const size_t base = ((size_t)(h * D + wrow_) * P.CPad + (size_t)kt * KT) * M::ES + wpc_ * 16;
+        const size_t part = (size_t)HD * P.CPad * M::ES;
+        wp0 = *reinterpret_cast<const uint4*>(wq + base);
+        wp1 = *reinterpret_cast<const uint4*>(wq + base + part);
+        wp2 = *reinterpret_cast<const uint4*>(wq + base + 2 * part);
     };
     auto wput = [&]() {
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int i = tid + 256 * j;
-            *reinterpret_cast<uint4*>(ws + (i >> 3) * RS + (i & 7) * 16) = wpre[j];
-        }
+        char* dst = ws + wrow_ * RS + wpc_ * 16;
+        *reinterpret_cast<uint4*>(dst) = wp0;
+        *reinterpret_cast<uint4*>(dst + 32 * RS) = wp1;
+        *reinterpret_cast<uint4*>(dst + 64 * RS) = wp2;
     };
     if (x_resident) stage_x(0);
     wfetch(0, 0);
@@ -233,6 +233,185 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs P) {
     }
 }
 
+
+// Register-resident variant for sequences of <= 16 tokens (the temporal attention of every shipped config).
+// Wave w owns sequence w of the workgroup (16 token rows) end to end.  The 16x16 accumulator layout (lane (c, q) holds
+// rows 4q..4q+3) is exactly the K-slot layout of a K = 16 MFMA operand, so
+//   S^T[j,i]  = sum_d K[j,d] Q[i,d]      : operands = the k / q accumulator tiles of GEMM1 (two d tiles)
+//   O^T[d,i]  = sum_j V^T[d,j] P^T[j,i]  : A = the v accumulator (GEMM1 run with swapped operands: tokens on the rows),
+//                                          B = the normalised scores, still in their accumulator registers
+//   y[c,i]   += sum_d Wo[c, h*32+d] O^T[d,i] : B = the O^T accumulator tiles, A = 4-element weight fragments from L2
+// never leave the register file: no q/k/v/P/O round trips through LDS, two workgroup barriers per head (weight tile only).
+template <int MODE, int TMA>            // TMA = C / 16 output-channel tiles (all owned by every wave, for its 16 rows)
+__global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
+    using M = Mma<MODE>;
+    constexpr int KT = M::KT, RS = ROW_STRIDE;
+    constexpr int APIECES = KT / 4;
+    constexpr int D = 32;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long* rowoff = reinterpret_cast<long*>(smem);               // [64]
+    char* xs = smem + 512;                                      // [64][RS]
+    char* ws = xs + 64 * RS;                                    // [96][RS]
+    constexpr int WOS = D * M::ES + 16;                         // Wo[:, head] slice rows: 32 k-elements + pad (conflict-free 8/16-byte reads)
+    constexpr int PPR = D * M::ES / 16;                         // 16-byte pieces per slice row
+    char* wos = ws + 96 * RS;                                   // [C][WOS]
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    const int HD = P.heads * D;
+    if (tid < 64) {
+        const int sl = tid >> 4, tok = tid & 15;
+        const long sg = (long)blockIdx.x * 4 + sl;
+        long off = -1;
+        if (sg < P.nseq && tok < P.L) off = (sg / P.inner) * P.outer_stride + (sg % P.inner) * P.inner_stride + (long)tok * P.tok_stride;
+        rowoff[tid] = off;
+    }
+    __syncthreads();
+
+    f32x4 oacc[TMA];
+#pragma unroll
+    for (int i = 0; i < TMA; ++i) oacc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* wq = reinterpret_cast<const char*>(P.wqkv);
+    const char* wo = reinterpret_cast<const char*>(P.wo);
+    const int nkt = P.CPad / KT;
+    const bool x_resident = (nkt == 1);
+    auto stage_x = [&](int kt) {
+        for (int i = tid; i < 64 * APIECES; i += 256) {
+            const int row = i / APIECES, pc = i % APIECES;
+            const int c = kt * KT + pc * 4;
+            const long ro = rowoff[row];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ro >= 0 && c < P.C) v = *reinterpret_cast<const float4*>(P.x + ro + c);
+            M::store4(xs + row * RS, pc * 4, v);
+        }
+    };
+    // three named registers (an indexed array here ends up in scratch memory)
+    uint4 wp0 = make_uint4(0, 0, 0, 0), wp1 = wp0, wp2 = wp0;
+    const int wrow_ = tid >> 3, wpc_ = tid & 7;                       // piece j covers weight-tile row wrow_ + 32 j  (part j = q,k,v)
+    auto wfetch = [&](int h, int kt) {
+        const size_t base = ((size_t)(h * D + wrow_) * P.CPad + (size_t)kt * KT) * M::ES + wpc_ * 16;
+        const size_t part = (size_t)HD * P.CPad * M::ES;
+        wp0 = *reinterpret_cast<const uint4*>(wq + base);
+        wp1 = *reinterpret_cast<const uint4*>(wq + base + part);
+        wp2 = *reinterpret_cast<const uint4*>(wq + base + 2 * part);
+    };
+    auto wput = [&]() {
+        char* dst = ws + wrow_ * RS + wpc_ * 16;
+        *reinterpret_cast<uint4*>(dst) = wp0;
+        *reinterpret_cast<uint4*>(dst + 32 * RS) = wp1;
+        *reinterpret_cast<uint4*>(dst + 64 * RS) = wp2;
+    };
+    if (x_resident) stage_x(0);
+    wfetch(0, 0);
+
+    for (int h = 0; h < P.heads; ++h) {
+        // GEMM1 for this wave's 16 rows: q, k as [d rows][token cols]; v as [token rows][d cols] (operands swapped)
+        f32x4 aq[2], ak[2], av[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { aq[i] = ak[i] = av[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int kt = 0; kt < nkt; ++kt) {
+            __syncthreads();
+            if (!x_resident) stage_x(kt);
+            wput();
+            if (kt == 0)                                  // Wo[:, head h]: read by every wave below (previous head's readers passed the barrier above)
+                for (int i = tid; i < TMA * 16 * PPR; i += 256) {
+                    const int row = i / PPR, pc = i % PPR;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (row < P.C) v = *reinterpret_cast<const uint4*>(wo + ((size_t)row * P.HDPad + (size_t)h * D) * M::ES + pc * 16);
+                    *reinterpret_cast<uint4*>(wos + row * WOS + pc * 16) = v;
+                }
+            __syncthreads();
+            {
+                int nh = h, nk = kt + 1;
+                if (nk == nkt) { nk = 0; nh = h + 1; }
+                if (nh < P.heads && !(P.dbg & 2)) wfetch(nh, nk);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const uint4 xf = *reinterpret_cast<const uint4*>(xs + (w * 16 + lp) * RS + ch * 64 + q * 16);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const uint4 wqf = *reinterpret_cast<const uint4*>(ws + ((0 * 2 + t) * 16 + lp) * RS + ch * 64 + q * 16);
+                    const uint4 wkf = *reinterpret_cast<const uint4*>(ws + ((1 * 2 + t) * 16 + lp) * RS + ch * 64 + q * 16);
+                    const uint4 wvf = *reinterpret_cast<const uint4*>(ws + ((2 * 2 + t) * 16 + lp) * RS + ch * 64 + q * 16);
+                    M::mma(aq[t], wqf, xf);
+                    M::mma(ak[t], wkf, xf);
+                    M::mma(av[t], xf, wvf);                   // swapped: rows = tokens, cols = d
+                }
+            }
+        }
+        // biases (q, k: per row d = 4q+reg ; v: per column d = lp), q scale
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 bq = *reinterpret_cast<const float4*>(P.bqkv + h * D + t * 16 + 4 * q);
+            const float4 bk = *reinterpret_cast<const float4*>(P.bqkv + HD + h * D + t * 16 + 4 * q);
+            const float bv = P.bqkv[2 * HD + h * D + t * 16 + lp];
+            aq[t][0] = (aq[t][0] + bq.x) * P.scale; aq[t][1] = (aq[t][1] + bq.y) * P.scale;
+            aq[t][2] = (aq[t][2] + bq.z) * P.scale; aq[t][3] = (aq[t][3] + bq.w) * P.scale;
+            ak[t][0] += bk.x; ak[t][1] += bk.y; ak[t][2] += bk.z; ak[t][3] += bk.w;
+            av[t][0] += bv; av[t][1] += bv; av[t][2] += bv; av[t][3] += bv;
+        }
+        // S^T[j, i]: lane (i, q) holds keys j = 4q..4q+3
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+        M::mma16(s, ak[0], aq[0]);
+        M::mma16(s, ak[1], aq[1]);
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { if (4 * q + r >= P.L) s[r] = -1e30f; mx = fmaxf(mx, s[r]); }
+        mx = max_q(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s[r] = __expf(s[r] - mx); sum += s[r]; }
+        sum = reduce_q(sum);
+        const float inv = __builtin_amdgcn_rcpf(sum);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] *= inv;
+        // O^T[d, i] per d tile; then y += Wo[:, head h] . O
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            M::mma16(o, av[t], s);
+#pragma unroll
+            for (int tm = 0; tm < TMA; ++tm) {
+                const f32x4 a = M::load_w4(wos + (tm * 16 + lp) * WOS + (t * 16 + 4 * q) * M::ES);
+                M::mma16(oacc[tm], a, o);
+            }
+        }
+    }
+    // epilogue: + bias + residual, rows of this wave's sequence
+    const long ro = rowoff[w * 16 + lp];
+#pragma unroll
+    for (int tm = 0; tm < TMA; ++tm) {
+        const int co = tm * 16 + 4 * q;
+        if (co >= P.C || ro < 0) continue;
+        const float4 bo = *reinterpret_cast<const float4*>(P.bo + co);
+        float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(P.dbg & 4)) xr = *reinterpret_cast<const float4*>(P.x + ro + co);
+        float4 v;
+        v.x = oacc[tm][0] + bo.x + xr.x; v.y = oacc[tm][1] + bo.y + xr.y;
+        v.z = oacc[tm][2] + bo.z + xr.z; v.w = oacc[tm][3] + bo.w + xr.w;
+        if (!(P.dbg & 8)) *reinterpret_cast<float4*>(P.y + ro + co) = v;
+    }
+}
+
+template <int MODE, int TMA>
+static hipError_t launch_attn_reg_t(const AttnArgs& a, hipStream_t st) {
+    const size_t lds = 512 + (size_t)(64 + 96) * ROW_STRIDE + (size_t)TMA * 16 * (32 * Mma<MODE>::ES + 16);
+    const long blocks = (a.nseq + 3) / 4;
+    hipLaunchKernelGGL((attention_reg_kernel<MODE, TMA>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_attn_reg(const AttnArgs& a, hipStream_t st) {
+    if (a.C <= 64) return launch_attn_reg_t<MODE, 4>(a, st);
+    if (a.C <= 128) return launch_attn_reg_t<MODE, 8>(a, st);
+    if (a.C <= 256) return launch_attn_reg_t<MODE, 16>(a, st);
+    if (a.C <= 512) return launch_attn_reg_t<MODE, 32>(a, st);
+    return hipErrorInvalidValue;
+}
+
 template <int MODE, int LP, int TMO>
 static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t st) {
     constexpr int KC = Mma<MODE>::KC;
@@ -261,6 +440,8 @@ static hipError_t launch_attn_l(const AttnArgs& a, hipStream_t st) {
 
 template <int MODE>
 static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
+    static const bool use_reg = getenv("VDX_ATTN_LDS") == nullptr;        // debugging switch: force the LDS-staged kernel
+    if (a.L <= 16 && use_reg) return launch_attn_reg<MODE>(a, st);
     if (a.L <= 16) return launch_attn_l<MODE, 16>(a, st);
     if (a.L <= 32) return launch_attn_l<MODE, 32>(a, st);
     if (a.L <= 64) return launch_attn_l<MODE, 64>(a, st);
@@ -268,6 +449,7 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_attention(int mode, AttnArgs a, hipStream_t st) {
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VDX_ATTN_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     a.CPad = conv_cin_pad(mode, a.C);
     a.HDPad = conv_cin_pad(mode, a.heads * 32);
     return mode == MODE_F32 ? launch_attn_m<MODE_F32>(a, st) : launch_attn_m<MODE_BF16>(a, st);

@@ -54,6 +54,19 @@ template <> struct Mma<MODE_F32> {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
     }
+    // K = 16 step whose operands are fp32 register quadruples (lane (r,q) supplies k = 4q..4q+3): an accumulator tile of
+    // a previous MFMA (rows 4q+reg) is directly such an operand
+    static __device__ __forceinline__ void mma16(f32x4& acc, const f32x4& a, const f32x4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc, 0, 0, 0);
+    }
+    // 4 consecutive-K weights of one row as an fp32 quadruple (for mma16's A operand)
+    static __device__ __forceinline__ f32x4 load_w4(const char* p) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        return f32x4{v.x, v.y, v.z, v.w};
+    }
     // store 4 consecutive-k values v at element offset k (multiple of 4) of an LDS row
     static __device__ __forceinline__ void store4(char* row, int k, float4 v) {
         *reinterpret_cast<float4*>(row + k * 4) = v;
@@ -69,6 +82,15 @@ template <> struct Mma<MODE_BF16> {
     static constexpr int KT = 64;
     static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma16(f32x4& acc, const f32x4& a, const f32x4& b) {
+        const uint2 ua = make_uint2(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]));
+        const uint2 ub = make_uint2(pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3]));
+        acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, ua), __builtin_bit_cast(s16x4, ub), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 load_w4(const char* p) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
     }
     static __device__ __forceinline__ void store4(char* row, int k, float4 v) {
         uint2 u;

@@ -71,6 +71,7 @@ struct AttnArgs {
     long nseq, inner, inner_stride, outer_stride, tok_stride;
     float scale;
     int CPad, HDPad;                          // completed by the launcher
+    int dbg;                                  // timing-only ablation bits (env VDX_ATTN_DBG); 0 in normal use
 };
 hipError_t launch_attention(int mode, AttnArgs a, hipStream_t st);
 
