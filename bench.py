@@ -61,6 +61,14 @@ def conv_flops(layer, frames, batch):
     return 2.0 * batch * frames * s * s * cin * cout * taps
 
 
+def conv_bytes(layer, frames, batch, mode):
+    """Algorithmic HBM bytes of one conv launch: fp32 input + fp32 output + packed weights (SURVEY 8d op-level definition)."""
+    cin, cout, s, taps, kind = layer
+    so = s // 2 if kind == 'down' else (2 * s if kind == 'up' else s)
+    es = 2 if mode == 'bf16' else 4
+    return 4.0 * batch * frames * (s * s * cin + so * so * cout) + es * taps * cin * cout
+
+
 def time_conv_kernels(unet, frames, size, batch, mode, reps=5):
     """Roofline leg: replays every conv_igemm launch shape of one forward standalone, HIP events on the launch stream."""
     from video_diffusion_nnx_amd import ops
@@ -97,10 +105,11 @@ def time_conv_kernels(unet, frames, size, batch, mode, reps=5):
         e1.record(st)
         e1.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        sym = f'conv_igemm_kernel<{mode},{64 if cout <= 64 else 128}>'
+        mode_id = {'f32': 0, 'bf16': 1}[mode]                                              # rocprof prints the template arguments
+        sym = f'vdx::conv_igemm_kernel<{mode_id}, {64 if cout <= 64 else 128}, {2 if (cout <= 64 and kind == "down") else 4}>'
         launches = 4 if kind == 'up' else 1                                              # the 4 phases are one launch (grid.z)
-        d = per_symbol.setdefault(sym, dict(ms=0.0, flops=0.0, launches=0))
-        d['ms'] += ms; d['flops'] += conv_flops(layer, frames, batch); d['launches'] += 1
+        d = per_symbol.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        d['ms'] += ms; d['flops'] += conv_flops(layer, frames, batch); d['bytes'] += conv_bytes(layer, frames, batch, mode); d['launches'] += 1
         del x, w, pw
     return per_symbol
 
@@ -136,7 +145,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('VDX_BENCH_BATCH', 8)), help='videos per GPU')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('VDX_BENCH_BATCH', 16)), help='videos per GPU')
     ap.add_argument('--mode', default=os.environ.get('VDX_BENCH_MODE', 'bf16'), choices=['bf16', 'f32'])
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--frames', type=int, default=16)
@@ -213,13 +222,28 @@ def main():
         with torch.cuda.stream(stream):
             per = time_conv_kernels(unet, Fr, S, B, args.mode)
         sym, d = max(per.items(), key=lambda kv: kv[1]['ms'])
-        achieved = d['flops'] / d['launches'] / (d['ms'] / d['launches'] * 1e-3) / 1e12
-        peak = MFMA_PEAK_TFLOPS[args.mode]
-        line['roofline'] = {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s', 'frac': achieved / peak, 'traffic': None,
-                            'kernel': sym, 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
+        tflops = d['flops'] / (d['ms'] * 1e-3) / 1e12
+        gbs = d['bytes'] / (d['ms'] * 1e-3) / 1e9
+        mfma_peak = MFMA_PEAK_TFLOPS[args.mode]
+        # which roofline binds this kernel: arithmetic intensity against the machine balance (peak FLOP/s / peak B/s)
+        hbm_bound = (d['flops'] / d['bytes']) < (mfma_peak * 1e12) / (HBM_PEAK_GBS * 1e9)
+        traffic = None                                   # HBM bytes per launch from committed rocprofv3 PMC passes of THIS workload
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get('batch') == B and tj.get('mode') == args.mode and tj.get('dim') == args.dim and sym in tj.get('kernels', {}):
+                traffic = tj['kernels'][sym]['hbm_bytes_per_launch']
+        line['roofline'] = {'bound': 'hbm' if hbm_bound else 'mfma',
+                            'achieved': gbs if hbm_bound else tflops, 'peak': HBM_PEAK_GBS if hbm_bound else mfma_peak,
+                            'unit': 'GB/s' if hbm_bound else 'TFLOP/s', 'frac': (gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / mfma_peak),
+                            'traffic': traffic, 'kernel': sym, 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
+                            'avg_algorithmic_mb_per_launch': d['bytes'] / d['launches'] / 1e6,
                             'avg_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
+                            'arithmetic_intensity_flop_per_byte': d['flops'] / d['bytes'],
+                            'mfma_tflops': tflops, 'mfma_frac': tflops / mfma_peak, 'hbm_gbs': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS,
                             'share_of_step': d['ms'] / ms_per_step,
-                            'all_conv_symbols': {k: {'ms_per_step': v['ms'], 'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} for k, v in per.items()}}
+                            'all_conv_symbols': {k: {'ms_per_step': v['ms'], 'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
+                                                     'gbs': v['bytes'] / (v['ms'] * 1e-3) / 1e9} for k, v in per.items()}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('cpu_baseline leg (oracle on host cores) ...')
         line['cpu_baseline'] = cpu_baseline(args.dim, Fr, S)

@@ -51,6 +51,38 @@ __global__ __launch_bounds__(256) void sla_ctx_kernel(const SlaArgs P) {
     f32x4 cacc = f32x4{0.f, 0.f, 0.f, 0.f};            // ctx tile (dt = w>>1 rows d, et = w&1 cols e)
     const int dt = w >> 1, et = w & 1;
 
+    // weight tile (k | v rows of this head): resident across sub-tiles when C fits one K tile
+    const bool w_resident = (nkt == 1);
+    auto stage_w = [&](int kt) {
+        for (int i = tid; i < 64 * 8; i += 256) {
+            const int row = i >> 3, pc = i & 7;
+            const char* src = (row < 32 ? wk : wv) + ((size_t)(h * 32 + (row & 31)) * P.CPad + (size_t)kt * KT) * M::ES + pc * 16;
+            *reinterpret_cast<uint4*>(ws + row * RS + pc * 16) = *reinterpret_cast<const uint4*>(src);
+        }
+    };
+    // x sub-tile prefetched through registers one sub-tile ahead (resident-weight case: one K tile per sub-tile)
+    constexpr int XP = 64 * APIECES / 256;                  // float4 pieces per thread
+    float4 xpre[XP];
+    auto xfetch = [&](int r0, int kt) {
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const int i = tid + 256 * u;
+            const int row = i / APIECES, pc = i % APIECES;
+            const int c = kt * KT + pc * 4;
+            xpre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + row < P.N && c < P.C) xpre[u] = *reinterpret_cast<const float4*>(xf + (size_t)(r0 + row) * P.C + c);
+        }
+    };
+    auto xput = [&]() {
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const int i = tid + 256 * u;
+            M::store4(xs + (i / APIECES) * RS, (i % APIECES) * 4, xpre[u]);
+        }
+    };
+    if (w_resident) stage_w(0);
+    xfetch(chunk * R, 0);
+
     for (int sub = 0; sub < P.nsub; ++sub) {
         const int r0 = chunk * R + sub * 64;
         if (r0 >= P.N) break;                          // uniform across the workgroup
@@ -59,19 +91,14 @@ __global__ __launch_bounds__(256) void sla_ctx_kernel(const SlaArgs P) {
         for (int i = 0; i < 2; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         for (int kt = 0; kt < nkt; ++kt) {
             __syncthreads();
-            for (int i = tid; i < 64 * APIECES; i += 256) {
-                const int row = i / APIECES, pc = i % APIECES;
-                const int c = kt * KT + pc * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (r0 + row < P.N && c < P.C) v = *reinterpret_cast<const float4*>(xf + (size_t)(r0 + row) * P.C + c);
-                M::store4(xs + row * RS, pc * 4, v);
-            }
-            for (int i = tid; i < 64 * 8; i += 256) {
-                const int row = i >> 3, pc = i & 7;
-                const char* src = (row < 32 ? wk : wv) + ((size_t)(h * 32 + (row & 31)) * P.CPad + (size_t)kt * KT) * M::ES + pc * 16;
-                *reinterpret_cast<uint4*>(ws + row * RS + pc * 16) = *reinterpret_cast<const uint4*>(src);
-            }
+            xput();
+            if (!w_resident) stage_w(kt);
             __syncthreads();
+            {   // next x tile: next K tile of this sub-tile, or the first of the next sub-tile
+                int nk = kt + 1, nr0 = r0;
+                if (nk == nkt) { nk = 0; nr0 = r0 + 64; }
+                if (nr0 < P.N && nr0 < (chunk + 1) * R) xfetch(nr0, nk);
+            }
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 uint4 bf[2], af[2];
