@@ -1,59 +1,67 @@
-"""Sampling CLI -- same flags and YAML schema as the reference's sample.py (/root/reference/sample.py:17-119):
-    python sample.py --checkpoint-path DIR --step N --output-path OUT --config configs/config_v2_2.yaml
-                     [--seed S] [--batch-size B] [--load-ema-params]
-Extra (non-reference) flags: --mode {bf16,f32}, --random-init (sample from un-trained weights, no checkpoint)."""
+"""Sampling CLI for the MI355X path.  Accepts the reference CLI's flags (reference sample.py:19-62: --config,
+--output-path, --checkpoint-path, --step, --seed, --batch-size, --load-ema-params) and its YAML schema, then runs
+GaussianDiffusion.sample on the GPU and writes one GIF per video (batch-global min-max to uint8, 120 ms/frame).
+Extensions: --mode {bf16,f32}; --random-init (no checkpoint); --timesteps N (shorter chain for smoke runs)."""
 import argparse
 import logging
-from pathlib import Path
+import pathlib
 
-import numpy as np
 import yaml
 
-logging.basicConfig(level=logging.INFO, force=True)
+HERE = pathlib.Path(__file__).resolve().parent
+FLAGS = (   # (flag, kwargs)
+    ('--config', dict(type=str, default=str(HERE / 'configs' / 'config.yaml'), help='YAML with unet / diffusion / trainer sections')),
+    ('--output-path', dict(type=str, default=str(HERE / 'outputs'), help='where the sample_<i>.gif files go')),
+    ('--checkpoint-path', dict(type=str, default=None, help='checkpoint directory (required unless --random-init)')),
+    ('--step', dict(type=int, default=0, help='which saved step to load')),
+    ('--seed', dict(type=int, default=0, help='Philox seed of the sampling chain')),
+    ('--batch-size', dict(type=int, default=2, help='videos to draw')),
+    ('--load-ema-params', dict(action='store_true', help='sample from the EMA weights')),
+    ('--mode', dict(choices=('bf16', 'f32'), default='bf16', help='MFMA operand precision')),
+    ('--random-init', dict(action='store_true', help='skip the checkpoint, use freshly initialised weights')),
+    ('--timesteps', dict(type=int, default=None, help='override diffusion.timesteps')),
+)
+
+
+def build_models(cfg, mode, timesteps=None):
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+    from video_diffusion_nnx_amd.unet3d import Rngs, Unet3D
+    u, d = cfg['unet'], cfg['diffusion']
+    unet = Unet3D(dim=u['dim'], rngs=Rngs(u['rngs_seed']), dim_mults=tuple(u['dim_mults']), channels=u['channels'],
+                  use_bert_text_cond=u['use_bert_text_cond'], mode=mode)
+    gd = GaussianDiffusion(denoise_fn=unet, image_size=d['image_size'], num_frames=d['num_frames'], channels=d['channels'],
+                           timesteps=timesteps or d['timesteps'], loss_type=d['loss_type'])
+    return unet, gd
 
 
 def main(argv=None):
-    parser = argparse.ArgumentParser(description='Generate samples using diffusion model')
-    parser.add_argument('--config', type=str, default=str(Path(__file__).parent / 'configs' / 'config.yaml'), help='Path to the YAML config file')
-    parser.add_argument('--output-path', type=str, default=str(Path(__file__).parent / 'outputs'), help='Directory to save sampled GIFs')
-    parser.add_argument('--checkpoint-path', type=str, required=False, default=None, help='Path to the model checkpoint directory')
-    parser.add_argument('--step', type=int, default=0, help='Checkpoint step number to load')
-    parser.add_argument('--seed', type=int, default=0, help='Random seed for sampling')
-    parser.add_argument('--batch-size', type=int, default=2, help='Number of videos to generate')
-    parser.add_argument('--load-ema-params', action='store_true', default=False, help='Whether to load EMA parameters')
-    parser.add_argument('--mode', choices=['bf16', 'f32'], default='bf16', help='MFMA operand precision (extension)')
-    parser.add_argument('--random-init', action='store_true', help='skip checkpoint loading (extension, for smoke runs)')
-    parser.add_argument('--timesteps', type=int, default=None, help='override diffusion.timesteps (extension, for smoke runs)')
-    args = parser.parse_args(argv)
-    if not args.random_init and args.checkpoint_path is None:
-        parser.error('--checkpoint-path is required (or pass --random-init)')
+    logging.basicConfig(level=logging.INFO, force=True)
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    for flag, kw in FLAGS:
+        ap.add_argument(flag, **kw)
+    a = ap.parse_args(argv)
+    if a.checkpoint_path is None and not a.random_init:
+        ap.error('--checkpoint-path is required (or pass --random-init)')
 
     from video_diffusion_nnx_amd.checkpoint import load_checkpoint
-    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
     from video_diffusion_nnx_amd.media import video_array_to_gif, videos_to_uint8
-    from video_diffusion_nnx_amd.unet3d import Rngs, Unet3D
 
-    output_path = Path(args.output_path)
-    output_path.mkdir(parents=True, exist_ok=True)
-    logging.info(f'Loading configuration from: {args.config}')
-    with open(args.config) as f:
-        config = yaml.safe_load(f)
-    unet_cfg, diff_cfg = config['unet'], config['diffusion']
-    unet_model = Unet3D(dim=unet_cfg['dim'], rngs=Rngs(unet_cfg['rngs_seed']), dim_mults=tuple(unet_cfg['dim_mults']),
-                        channels=unet_cfg['channels'], use_bert_text_cond=unet_cfg['use_bert_text_cond'], mode=args.mode)
-    diffusion_model = GaussianDiffusion(denoise_fn=unet_model, image_size=diff_cfg['image_size'], num_frames=diff_cfg['num_frames'],
-                                        timesteps=args.timesteps or diff_cfg['timesteps'], loss_type=diff_cfg['loss_type'], channels=diff_cfg['channels'])
-    if not args.random_init:
-        checkpoint_path = Path(args.checkpoint_path).resolve()
-        diffusion_model, _ = load_checkpoint(diffusion_model, args.step, str(checkpoint_path), load_ema_params=args.load_ema_params)
-        logging.info(f'Loaded checkpoint from {checkpoint_path} at step {args.step}')
-    sampled_videos = diffusion_model.sample(args.seed, batch_size=args.batch_size)
-    logging.info(f'Sampled {len(sampled_videos)} videos')
-    uint8_videos = videos_to_uint8(sampled_videos.cpu().numpy())
-    for i, video_np in enumerate(uint8_videos):
-        output_filename = output_path / f'sample_{i}.gif'
-        video_array_to_gif(video_np, output_filename)
-        logging.info(f'Saved sample {i} to {output_filename}')
+    out_dir = pathlib.Path(a.output_path)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    with open(a.config) as fh:
+        cfg = yaml.safe_load(fh)
+    logging.info('config %s', a.config)
+    _, gd = build_models(cfg, a.mode, a.timesteps)
+    if not a.random_init:
+        ckpt = pathlib.Path(a.checkpoint_path).resolve()
+        gd, _ = load_checkpoint(gd, a.step, str(ckpt), load_ema_params=a.load_ema_params)
+        logging.info('restored step %d from %s', a.step, ckpt)
+    videos = gd.sample(a.seed, batch_size=a.batch_size)
+    logging.info('drew %d videos', len(videos))
+    for i, frames in enumerate(videos_to_uint8(videos.cpu().numpy())):
+        target = out_dir / f'sample_{i}.gif'
+        video_array_to_gif(frames, target)
+        logging.info('wrote %s', target)
 
 
 if __name__ == '__main__':

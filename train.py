@@ -1,27 +1,33 @@
-"""Training CLI -- same flags and YAML schema as the reference's train.py (/root/reference/train.py:14-121):
-    python train.py --config configs/config_v2_2.yaml [--resume_step N] [--rng_seed S]
-Multi-GPU: `python -m torch.distributed.run --nproc-per-node N train.py --config ...` (one process per GPU, RCCL);
-`train_batch_size` stays the GLOBAL batch, split over ranks as the reference splits it over devices (trainer.py:161-166).
-Keys missing from a YAML fall back to the Trainer defaults (the reference raises KeyError there).
-Extra (non-reference) flags: --mode {bf16,f32}, --train_num_steps (override, for smoke runs), --dataset_path."""
+"""Training CLI for the MI355X path.  Accepts the reference CLI's flags (reference train.py:23-42: --config,
+--resume_step, --rng_seed) and its YAML schema (unet / diffusion / trainer sections).  Keys a YAML leaves out fall back
+to the Trainer defaults (the reference indexes them and raises KeyError for its own v1_0..v2_2 files).
+Multi-GPU: `python -m torch.distributed.run --nproc-per-node N train.py --config ...` = one process per GPU over RCCL;
+`train_batch_size` stays the GLOBAL batch and is split over ranks like the reference splits it over devices.
+Extensions: --mode {bf16,f32}; --train_num_steps N; --dataset_path P (e.g. synthetic:64)."""
 import argparse
 import logging
 import os
-from pathlib import Path
+import pathlib
 
 import yaml
+
+HERE = pathlib.Path(__file__).resolve().parent
+FLAGS = (
+    ('--config', dict(type=str, default=str(HERE / 'configs' / 'config.yaml'), help='YAML with unet / diffusion / trainer sections')),
+    ('--resume_step', dict(type=int, default=0, help='restore params + EMA of this step first (optimizer state restarts)')),
+    ('--rng_seed', dict(type=int, default=None, help='master seed; default: config rng_seed, else 0')),
+    ('--mode', dict(choices=('bf16', 'f32'), default='bf16', help='MFMA operand precision')),
+    ('--train_num_steps', dict(type=int, default=None, help='override trainer.train_num_steps')),
+    ('--dataset_path', dict(type=str, default=None, help='override trainer.dataset_path')),
+)
 
 
 def main(argv=None):
     logging.basicConfig(level=logging.INFO, format='%(levelname)s:%(name)s:%(message)s', force=True)
-    parser = argparse.ArgumentParser(description='Train diffusion model')
-    parser.add_argument('--config', type=str, default=str(Path(__file__).parent / 'configs' / 'config.yaml'), help='Path to the YAML config file')
-    parser.add_argument('--resume_step', type=int, default=0, help='Step to resume training from')
-    parser.add_argument('--rng_seed', type=int, default=None, help='RNG seed to use for training')
-    parser.add_argument('--mode', choices=['bf16', 'f32'], default='bf16', help='MFMA operand precision (extension)')
-    parser.add_argument('--train_num_steps', type=int, default=None, help='override trainer.train_num_steps (extension)')
-    parser.add_argument('--dataset_path', type=str, default=None, help='override trainer.dataset_path, e.g. synthetic:64 (extension)')
-    args = parser.parse_args(argv)
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    for flag, kw in FLAGS:
+        ap.add_argument(flag, **kw)
+    a = ap.parse_args(argv)
 
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -32,30 +38,23 @@ def main(argv=None):
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
 
-    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+    from sample import build_models
     from video_diffusion_nnx_amd.trainer import Trainer
-    from video_diffusion_nnx_amd.unet3d import Rngs, Unet3D
 
-    logging.info(f'Loading configuration from: {args.config}')
-    with open(args.config) as f:
-        config = yaml.safe_load(f)
-    master_seed = args.rng_seed if args.rng_seed is not None else config.get('rng_seed', 0)
-    logging.info(f'Using master RNG seed: {master_seed}')
-    unet_cfg, diff_cfg, tc = config['unet'], config['diffusion'], dict(config['trainer'])
-    unet_model = Unet3D(dim=unet_cfg['dim'], rngs=Rngs(unet_cfg['rngs_seed']), dim_mults=tuple(unet_cfg['dim_mults']),
-                        channels=unet_cfg['channels'], use_bert_text_cond=unet_cfg['use_bert_text_cond'], mode=args.mode)
-    diffusion_model = GaussianDiffusion(denoise_fn=unet_model, image_size=diff_cfg['image_size'], num_frames=diff_cfg['num_frames'],
-                                        timesteps=diff_cfg['timesteps'], loss_type=diff_cfg['loss_type'], channels=diff_cfg['channels'])
-    if args.train_num_steps is not None:
-        tc['train_num_steps'] = args.train_num_steps
-    if args.dataset_path is not None:
-        tc['dataset_path'] = args.dataset_path
-    tc.pop('resume_training_step', None)                       # the CLI flag wins, as in the reference (train.py:101)
-    folder = tc.pop('folder')
-    trainer = Trainer(diffusion_model=diffusion_model, folder=folder, resume_training_step=args.resume_step, rng_seed=master_seed, **tc)
-    logging.info('Starting training...')
+    with open(a.config) as fh:
+        cfg = yaml.safe_load(fh)
+    seed = a.rng_seed if a.rng_seed is not None else cfg.get('rng_seed', 0)
+    logging.info('config %s, master seed %s', a.config, seed)
+    _, gd = build_models(cfg, a.mode)
+    tc = dict(cfg['trainer'])
+    if a.train_num_steps is not None:
+        tc['train_num_steps'] = a.train_num_steps
+    if a.dataset_path is not None:
+        tc['dataset_path'] = a.dataset_path
+    tc.pop('resume_training_step', None)             # the command-line flag wins, as in the reference
+    trainer = Trainer(diffusion_model=gd, folder=tc.pop('folder'), resume_training_step=a.resume_step, rng_seed=seed, **tc)
     trainer.train()
-    logging.info('Training finished.')
+    logging.info('done')
     if world > 1:
         dist.destroy_process_group()
 

@@ -21,6 +21,7 @@
 namespace vdx {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned OOB = 0xFFFFFFF0u;      // buffer-load offset beyond num_records: the hardware returns zeros
 
 // TN = 16-pixel tiles per wave (4: 64 pixels, 2: 32 pixels).  Workgroup tile = BC channels x BM pixels.
@@ -34,6 +35,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
     constexpr int TM = 4;
     constexpr int APIECES = KT / 4;                 // float4 pieces per staged pixel row
     constexpr int WREGS = BC * 8 / 256;             // 16-byte weight pieces per thread per tap
+    constexpr int AU = 4;                           // halo-tile loads in flight per thread (one or two batches per tile)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -164,23 +166,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
     wload(0, 0, 0);
     for (int cc = 0; cc < nchunks; ++cc) {
         if (cc) __syncthreads();                     // every wave is done reading the previous halo tile
-        for (int i0 = tid; i0 < total; i0 += 1024) {
-            u32x4 v[4];
+        for (int i0 = tid; i0 < total; i0 += 256 * AU) {
+            u32x4 v[AU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < AU; ++u) {
                 const int i = i0 + 256 * u;
                 const int hp = i / APIECES, pc = i % APIECES;
                 const int c = cc * KT + pc * 4;
                 const int pix = (i < total) ? hp_pix[hp] : -1;
-                const unsigned o0 = (pix >= 0 && c < P.C0) ? (unsigned)(pix * P.C0 + c) * 4u : OOB;
-                v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0);
+                if (P.x0_bf16) {                       // bf16-stored input (intra-ResnetBlock tensor): 4 channels = 8 bytes
+                    const unsigned o0 = (pix >= 0 && c < P.C0) ? (unsigned)(pix * P.C0 + c) * 2u : OOB;
+                    const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rs0, o0, 0, 0);
+                    v[u] = u32x4{h2.x << 16, h2.x & 0xFFFF0000u, h2.y << 16, h2.y & 0xFFFF0000u};
+                } else {
+                    const unsigned o0 = (pix >= 0 && c < P.C0) ? (unsigned)(pix * P.C0 + c) * 4u : OOB;
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0);
+                }
                 if (P.C1) {
                     const unsigned o1 = (pix >= 0 && c >= P.C0 && c < Cin) ? (unsigned)(pix * P.C1 + (c - P.C0)) * 4u : OOB;
                     v[u] |= __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < AU; ++u) {
                 const int i = i0 + 256 * u;
                 if (i < total) {
                     const int hp = i / APIECES, pc = i % APIECES;
@@ -242,7 +250,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
                     const float4 r4 = *reinterpret_cast<const float4*>(P.res + (size_t)gout[tn] * P.Cout + co);
                     v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                 }
-                *reinterpret_cast<float4*>(P.y + (size_t)gout[tn] * P.Cout + co) = v;
+                if (P.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.y) + ((size_t)gout[tn] * P.Cout + co) * 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                else *reinterpret_cast<float4*>(P.y + (size_t)gout[tn] * P.Cout + co) = v;
                 s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
                 ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
             }
@@ -366,7 +375,7 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     const int ES = mode == MODE_F32 ? 4 : 2;
     const size_t npix = (size_t)a.NF * a.H * a.W;
     if (a.wrows <= 0) { a.wrows = a.Cout; a.wrow0 = 0; }
-    const size_t b0 = npix * a.C0 * 4, b1 = npix * a.C1 * 4, bw = (size_t)(a.kind ? 16 : a.kh * a.kw) * a.wrows * a.CinPad * ES;
+    const size_t b0 = npix * a.C0 * (a.x0_bf16 ? 2 : 4), b1 = npix * a.C1 * 4, bw = (size_t)(a.kind ? 16 : a.kh * a.kw) * a.wrows * a.CinPad * ES;
     if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
     a.x0_bytes = (unsigned)b0; a.x1_bytes = (unsigned)b1; a.w_bytes = (unsigned)bw;
     // variant: 64-channel tiles take 256 pixels per workgroup (stride 1) so every wave owns a 64x64 tile

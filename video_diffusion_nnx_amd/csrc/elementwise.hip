@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void resblock_tail_kernel(TailArgs P) {
         for (int v = 0; v < VPL; ++v) {
             const int c = (v * LPP + sub) * 4;
             if (c < C) {
-                const float4 y = *reinterpret_cast<const float4*>(P.y2 + base + c);
+                const float4 y = load4_f32_or_bf16(P.y2, base + c, P.y2_bf16);
                 const float4 a = *reinterpret_cast<const float4*>(coefA + c);
                 const float4 d = *reinterpret_cast<const float4*>(coefD + c);
                 const float4 lg = *reinterpret_cast<const float4*>(P.ln_gamma + c);

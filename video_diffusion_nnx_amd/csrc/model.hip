@@ -345,6 +345,8 @@ static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, 
     a.NF = f.B * m->cfg.num_frames; a.F = m->cfg.num_frames; a.H = S; a.W = S;
     a.kind = 0; a.kh = a.kw = 3; a.stride = 1; a.pad = 1;
     a.out_stats = f.stat(r.st1); a.out_groups = G;
+    const int half = (m->mode == MODE_BF16);                  // bf16 mode stores the two intra-block tensors y1, y2 as bf16
+    a.y_bf16 = half;
     hipError_t e = launch_conv(m->mode, a, f.st);
     if (e != hipSuccess) return e;
     ConvArgs b;
@@ -352,6 +354,7 @@ static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, 
     b.x0 = f.slot(r.s_y1); b.C0 = r.cout;
     b.wp = f.pk + r.pk_b2; b.bias = f.p + r.b2_b; b.y = f.slot(r.s_y2); b.Cout = r.cout;
     b.NF = a.NF; b.F = a.F; b.H = S; b.W = S; b.kind = 0; b.kh = b.kw = 3; b.stride = 1; b.pad = 1;
+    b.x0_bf16 = half; b.y_bf16 = half;
     b.pro = 1; b.in_stats = f.stat(r.st1); b.gamma = f.p + r.b1_gs; b.beta = f.p + r.b1_gb; b.groups = G;
     if (r.has_mlp) { b.ss = f.ss + (size_t)m->ss_layers[r.ss_index].out_off * f.B; b.ss_stride = 2 * r.cout; }
     b.out_stats = f.stat(r.st2); b.out_groups = G;
@@ -370,7 +373,7 @@ static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, 
     }
     TailArgs t;
     memset(&t, 0, sizeof(t));
-    t.y2 = f.slot(r.s_y2); t.r = rsrc; t.out = f.slot(r.s_out);
+    t.y2 = f.slot(r.s_y2); t.y2_bf16 = half; t.r = rsrc; t.out = f.slot(r.s_out);
     t.stats = f.stat(r.st2); t.gn_gamma = f.p + r.b2_gs; t.gn_beta = f.p + r.b2_gb; t.groups = G;
     t.ln_gamma = f.p + r.n2_s; t.ln_beta = f.p + r.n2_b;
     t.C = r.cout; t.batch = f.B; t.pix_per_sample = (long)m->cfg.num_frames * S * S;

@@ -53,7 +53,7 @@ void wgrad(Bwd& b, const float* x0, int c0, const float* x1, int c1, const float
     a.x0 = x0; a.x1 = x1; a.C0 = c0; a.C1 = c1; a.dy = dy; a.Cout = Cout; a.dW = b.grads + w_off; a.db = b_off >= 0 ? b.grads + b_off : nullptr;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl_in);
     a.kind = kind; a.kh = a.kw = kind ? 4 : k; a.stride = kind ? 1 : stride;
-    if (in_stats) { a.pro = 1; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta; a.groups = b.m->cfg.resnet_groups; a.ss = ss; a.ss_stride = ss_stride; }
+    if (in_stats) { a.x0_bf16 = (b.m->mode == MODE_BF16); a.pro = 1; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta; a.groups = b.m->cfg.resnet_groups; a.ss = ss; a.ss_stride = ss_stride; }
     b.ok(launch_conv_wgrad(a, b.st));
 }
 
@@ -69,7 +69,7 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     // 1. tail: out = SiLU(GN2(y2)) + LN(r)
     NormBwdArgs t;
     memset(&t, 0, sizeof(t));
-    t.dact = g; t.y = b.slot(r.s_y2); t.dy = L.t1; t.stats = b.stat(r.st2); t.gamma = b.p + r.b2_gs; t.beta = b.p + r.b2_gb; t.groups = G;
+    t.dact = g; t.y = b.slot(r.s_y2); t.y_bf16 = (m->mode == MODE_BF16); t.dy = L.t1; t.stats = b.stat(r.st2); t.gamma = b.p + r.b2_gs; t.beta = b.p + r.b2_gb; t.groups = G;
     t.d_gamma = b.grads + r.b2_gs; t.d_beta = b.grads + r.b2_gb;
     t.r = rsrc; t.ln_gamma = b.p + r.n2_s; t.dr = L.t2; t.d_ln_gamma = b.grads + r.n2_s; t.d_ln_beta = b.grads + r.n2_b;
     t.R = b.normscr; t.G = b.normscr + (size_t)b.B * r.cout * 2; t.C = r.cout; t.batch = b.B; t.pix_per_sample = b.pix(lvl);
@@ -81,7 +81,7 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     // 3. prologue: act1 = SiLU((GN1(y1))*(1+s)+sh)
     NormBwdArgs q;
     memset(&q, 0, sizeof(q));
-    q.dact = L.t3; q.y = b.slot(r.s_y1); q.dy = L.t1; q.stats = b.stat(r.st1); q.gamma = b.p + r.b1_gs; q.beta = b.p + r.b1_gb; q.groups = G;
+    q.dact = L.t3; q.y = b.slot(r.s_y1); q.y_bf16 = (m->mode == MODE_BF16); q.dy = L.t1; q.stats = b.stat(r.st1); q.gamma = b.p + r.b1_gs; q.beta = b.p + r.b1_gb; q.groups = G;
     q.ss = ssrow; q.ss_stride = 2 * r.cout; q.d_gamma = b.grads + r.b1_gs; q.d_beta = b.grads + r.b1_gb;
     q.dss = r.has_mlp ? b.dss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
     q.R = b.normscr; q.G = b.normscr + (size_t)b.B * r.cout * 2; q.C = r.cout; q.batch = b.B; q.pix_per_sample = b.pix(lvl);

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs P) {
         for (int v = 0; v < VPL; ++v) {
             const int c = (v * LPP + sub) * 4;
             if (c < C) {
-                const float4 y = *reinterpret_cast<const float4*>(P.y + base + c);
+                const float4 y = load4_f32_or_bf16(P.y, base + c, P.y_bf16);
                 const float4 da = *reinterpret_cast<const float4*>(P.dact + base + c);
                 const float yv[4] = {y.x, y.y, y.z, y.w}, dv[4] = {da.x, da.y, da.z, da.w};
                 float* p0 = &r0[v].x; float* p1 = &r1[v].x;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs P) {
         for (int v = 0; v < VPL; ++v) {
             const int c = (v * LPP + sub) * 4;
             if (c < C) {
-                const float4 y = *reinterpret_cast<const float4*>(P.y + base + c);
+                const float4 y = load4_f32_or_bf16(P.y, base + c, P.y_bf16);
                 const float yv[4] = {y.x, y.y, y.z, y.w}, dv[4] = {da[v].x, da[v].y, da[v].z, da[v].w};
                 float o[4];
 #pragma unroll

@@ -104,6 +104,13 @@ template <> struct Mma<MODE_BF16> {
     }
 };
 
+// 4 consecutive channels of a tensor stored as fp32 or bf16 (element index i, a multiple of 4)
+__device__ __forceinline__ float4 load4_f32_or_bf16(const float* base, size_t i, int is_bf16) {
+    if (!is_bf16) return *reinterpret_cast<const float4*>(base + i);
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(base) + i * 2);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
+}
+
 // sum over the 16 lanes that share (lane >> 4)
 __device__ __forceinline__ float reduce16(float v) {
     v += __shfl_xor(v, 1);

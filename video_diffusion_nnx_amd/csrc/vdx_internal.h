@@ -27,6 +27,7 @@ struct ConvArgs {
     const float* ss; int ss_stride; // per-sample [scale(Cin) | shift(Cin)] rows, or null
     // epilogue: GroupNorm partial statistics of the output (or null)
     double* out_stats; int out_groups;
+    int x0_bf16, y_bf16;            // x0 / y are stored as bf16 (the intra-ResnetBlock tensors in bf16 mode); y_bf16 excludes res
     const float* res;               // optional residual added to the output: y = conv + bias + res  ([.., Cout] like y)
     int wrows, wrow0;               // packed weight rows per tap / first row (0,0 = Cout rows from 0): slices a wider packing
     // completed by launch_conv
@@ -37,6 +38,7 @@ struct ConvArgs {
 // out = SiLU(GroupNorm(y2; stats, gn_gamma, gn_beta)) + LayerNorm_C(r; ln_gamma, ln_beta), channel-last [B][pix][C]
 struct TailArgs {
     const float* y2; const float* r; float* out;
+    int y2_bf16;                    // y2 stored as bf16
     const double* stats; const float* gn_gamma; const float* gn_beta; int groups;
     const float* ln_gamma; const float* ln_beta;
     int C; int batch; long pix_per_sample;
@@ -118,6 +120,7 @@ struct WgradArgs {
     int NF, F, H, W;                                       // input geometry
     int kind, kh, kw, stride;
     int pro; const double* in_stats; const float* gamma; const float* beta; int groups; const float* ss; int ss_stride;
+    int x0_bf16;                                           // x0 stored as bf16
     // completed by the launcher
     int taps, sa, sb, ext, halo, Hm, Wm, Hy, Wy, PH, PW, co_tiles;
 };
@@ -128,6 +131,7 @@ hipError_t launch_add_inplace(float* y, const float* x, long n, hipStream_t st);
 // Backward of  act = SiLU((gamma*GN(y)+beta)*(1+s)+sh)  [+ LayerNorm_C(r) branch of the block tail]; channel-last [B][pix][C]
 struct NormBwdArgs {
     const float* dact; const float* y; float* dy;                 // dL/dact (or dL/dout), saved pre-norm tensor, result dL/dy
+    int y_bf16;                                                   // y stored as bf16
     const double* stats; const float* gamma; const float* beta; int groups;
     const float* ss; int ss_stride;                               // forward scale/shift rows or null
     float* d_gamma; float* d_beta;                                // accumulated (atomics)

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin) {
                 const size_t pix = ((size_t)f * P.H + gy) * P.W + gx;
-                v = (c < P.C0) ? *reinterpret_cast<const float4*>(P.x0 + pix * P.C0 + c)
+                v = (c < P.C0) ? load4_f32_or_bf16(P.x0, pix * P.C0 + c, P.x0_bf16)
                                : *reinterpret_cast<const float4*>(P.x1 + pix * P.C1 + (c - P.C0));
                 if (P.pro) {
                     const float4 a = *reinterpret_cast<const float4*>(coefA + pc * 4);
