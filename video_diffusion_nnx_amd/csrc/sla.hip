@@ -6,13 +6,14 @@
 //   k = softmax_N(x Wk)   (over the N pixels)
 //   ctx[d,e] = sum_n k[d,n] v[e,n] ;  out[e,n] = sum_d ctx[d,e] q[d,n] ;  y = to_out(out) + x
 // Three launches, none of which writes q/k/v to HBM:
-//   sla_ctx_kernel     (frame, pixel-chunk, head): K/V projection of 64-pixel sub-tiles, ONLINE softmax over
+//   sla_ctx_kernel     (frame, pixel-chunk, head; heads of a chunk co-scheduled on one XCD): K/V projection of 64-pixel sub-tiles, ONLINE softmax over
 //                      pixels (running max / sum / rescaled 32x32 context in the accumulators) -> partial
 //   sla_combine_kernel (frame, head): merges the chunk partials, normalises, emits ctx^T in the MMA type
 //   sla_out_kernel     (frame, 64 pixels): Q projection of all heads, softmax over D with wavefront
 //                      shuffles, out = ctx^T q, to_out GEMM accumulated in registers, + residual
 #include "vdx_common.h"
 #include "vdx_internal.h"
+#include <stdlib.h>
 
 namespace vdx {
 
@@ -39,8 +40,15 @@ __global__ __launch_bounds__(256) void sla_ctx_kernel(const SlaArgs P) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lp = lane & 15, q = lane >> 4;
     const int wc = w & 1, wr = w >> 1;
-    const int h = blockIdx.y;
-    const int n = blockIdx.x / P.nchunk, chunk = blockIdx.x % P.nchunk;
+    // XCD-aware block order: workgroup ids are dealt round-robin to the 8 XCDs, so inside each group of 8*heads ids the
+    // blocks {j, j+8, j+16, ...} share an XCD (and its L2) and run at the same time: give them the heads of ONE pixel
+    // chunk, so x is fetched from HBM once instead of once per head.
+    const int gsz = 8 * P.heads;
+    const int grp = blockIdx.x / gsz, j = blockIdx.x % gsz;
+    const int h = j >> 3;
+    const int cidx = grp * 8 + (j & 7);
+    if (cidx >= P.NF * P.nchunk) return;               // uniform across the workgroup
+    const int n = cidx / P.nchunk, chunk = cidx % P.nchunk;
     const int R = P.nsub * 64;
     const float* xf = P.x + (size_t)n * P.N * P.C;
     const int nkt = P.CPad / KT;
@@ -359,6 +367,299 @@ __global__ __launch_bounds__(256) void sla_out_kernel(const SlaArgs P) {
     }
 }
 
+// ---- one wave per head: the kernels used when heads == 8 and the x tile fits the LDS double buffer -----------------
+// Workgroup = (frame, chunk of nsub 64-pixel sub-tiles), 8 waves, wave h = head h.  The fp32 x sub-tile is fetched once for
+// all heads (registers one sub-tile ahead -> LDS ring of 2), every head's projection weights stay in registers as MFMA
+// fragments for the whole chunk, and the projections are oriented so that their accumulators are directly the operands
+// of the following K=16 MFMA (Mma::mma16): no q/k/v transposes through LDS, one barrier per sub-tile.
+
+template <int MODE, int NKT>
+struct SlaTile {
+    using M = Mma<MODE>;
+    static constexpr int APIECES = M::KT / 4;                 // float4 pieces per pixel per K tile
+    static constexpr int XP = 64 * APIECES * NKT / 512;       // pieces per thread
+    static constexpr int PLANE = 64 * ROW_STRIDE;             // one K tile of a sub-tile: [64 pixels][ROW_STRIDE]
+    static constexpr int BUF = NKT * PLANE;
+    float4 xpre[XP];
+    __device__ __forceinline__ void fetch(const float* xf, int r0, int N, int C, int tid) {
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const int i = tid + 512 * u;
+            const int kt = i / (64 * APIECES), rem = i % (64 * APIECES);
+            const int row = rem / APIECES, c = kt * M::KT + (rem % APIECES) * 4;
+            xpre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + row < N && c < C) xpre[u] = *reinterpret_cast<const float4*>(xf + (size_t)(r0 + row) * C + c);
+        }
+    }
+    __device__ __forceinline__ void put(char* xs, int tid) const {
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            const int i = tid + 512 * u;
+            const int kt = i / (64 * APIECES), rem = i % (64 * APIECES);
+            M::store4(xs + kt * PLANE + (rem / APIECES) * ROW_STRIDE, (rem % APIECES) * 4, xpre[u]);
+        }
+    }
+};
+
+template <int MODE, int NKT>
+__global__ __launch_bounds__(512) void sla_ctx8_kernel(const SlaArgs P) {
+    using M = Mma<MODE>;
+    using T = SlaTile<MODE, NKT>;
+    constexpr int RS = ROW_STRIDE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // xs[2][NKT][64][RS]
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    const int n = blockIdx.x / P.nchunk, chunk = blockIdx.x % P.nchunk;
+    const int R = P.nsub * 64;
+    const float* xf = P.x + (size_t)n * P.N * P.C;
+
+    // this head's K (tm 0,1) and V (tm 2,3) projection rows as B-operand fragments, resident for the whole chunk
+    uint4 wf[NKT][2][4];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                const char* base = reinterpret_cast<const char*>(tm < 2 ? P.wk : P.wv);
+                wf[kt][ch][tm] = *reinterpret_cast<const uint4*>(base + ((size_t)(h * 32 + (tm & 1) * 16 + lp) * P.CPad + kt * M::KT) * M::ES + ch * 64 + q * 16);
+            }
+    float m_run[2] = {-1e30f, -1e30f}, s_run[2] = {0.f, 0.f};
+    f32x4 cacc[2][2];                                  // ctx^T tiles [et][dt]: lane (lp, q) = (d = dt*16+lp, e = et*16+4q+r)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { cacc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; cacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    T t;
+    t.fetch(xf, chunk * R, P.N, P.C, tid);
+    t.put(smem, tid);
+    __syncthreads();
+    for (int sub = 0; sub < P.nsub; ++sub) {
+        const int r0 = chunk * R + sub * 64;
+        if (r0 >= P.N) break;                          // uniform across the workgroup
+        const char* xs = smem + (sub & 1) * T::BUF;
+        const bool more = (sub + 1 < P.nsub) && (r0 + 64 < P.N);
+        if (more) t.fetch(xf, r0 + 64, P.N, P.C, tid);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {               // two 32-pixel online-softmax steps per sub-tile
+            f32x4 acc[2][4];                           // [pixel tile][k0 k1 v0 v1]: lane (lp, q) = (channel lp, pixels 4q+r)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    uint4 xa[2];
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        xa[tn] = *reinterpret_cast<const uint4*>(xs + kt * T::PLANE + ((hf * 2 + tn) * 16 + lp) * RS + ch * 64 + q * 16);
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                        for (int tm = 0; tm < 4; ++tm) M::mma(acc[tn][tm], xa[tn], wf[kt][ch][tm]);
+                }
+            bool valid[2][4];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) valid[tn][r] = (r0 + (hf * 2 + tn) * 16 + 4 * q + r) < P.N;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {           // softmax over pixels of channel d = dt*16+lp
+                float mx = -1e30f;
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, valid[tn][r] ? acc[tn][dt][r] : -1e30f);
+                mx = max_q(mx);
+                const float mn = fmaxf(m_run[dt], mx);
+                const float alpha = __expf(m_run[dt] - mn);
+                m_run[dt] = mn;
+                float ssum = 0.f;
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = valid[tn][r] ? __expf(acc[tn][dt][r] - mn) : 0.f;
+                        acc[tn][dt][r] = e;
+                        ssum += e;
+                    }
+                s_run[dt] = s_run[dt] * alpha + reduce_q(ssum);
+#pragma unroll
+                for (int et = 0; et < 2; ++et)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cacc[et][dt][r] *= alpha;
+            }
+            // ctx^T[e, d] += sum_n v[e, n] e_k[d, n]: both operands are the accumulators above (k = pixel 4q+r);
+            // invalid pixels contribute v = 0 (x rows zero-filled, no bias) and e_k = 0
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int et = 0; et < 2; ++et)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) M::mma16(cacc[et][dt], acc[tn][2 + et], acc[tn][dt]);
+        }
+        if (more) t.put(smem + ((sub + 1) & 1) * T::BUF, tid);
+        __syncthreads();
+    }
+    float* part = P.part + ((size_t)(n * P.nchunk + chunk) * P.heads + h) * SLA_PART;
+#pragma unroll
+    for (int et = 0; et < 2; ++et)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+            *reinterpret_cast<float4*>(part + (dt * 16 + lp) * 32 + et * 16 + 4 * q) =
+                make_float4(cacc[et][dt][0], cacc[et][dt][1], cacc[et][dt][2], cacc[et][dt][3]);
+    if (q == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) { part[1024 + dt * 16 + lp] = m_run[dt]; part[1056 + dt * 16 + lp] = s_run[dt]; }
+    }
+}
+
+// q projection + softmax over D + out = ctx^T q per head in registers; the heads meet in LDS (os) for the to_out GEMM,
+// which the 8 waves split by (output-channel tile, pixel tile).  TMO x TNO = tiles per wave: C/16 * 4 / 8.
+template <int MODE, int NKT, int TMO, int TNO>
+__global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const SlaArgs P) {
+    using M = Mma<MODE>;
+    using T = SlaTile<MODE, NKT>;
+    constexpr int RS = ROW_STRIDE, KC = M::KC, HD = 256;
+    constexpr int RSO = HD * M::ES + 16;
+    constexpr int NCHO = HD / KC;
+    constexpr bool WO_RES = (TMO * NCHO <= 16);        // to_out fragments register-resident
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // xs[2][NKT][64][RS] | os[64][RSO]
+    char* os = smem + 2 * T::BUF;
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    const int n = blockIdx.x / P.nchunk, chunk = blockIdx.x % P.nchunk;
+    const int R = P.nsub * 64;
+    const float* xf = P.x + (size_t)n * P.N * P.C;
+    float* yf = P.y + (size_t)n * P.N * P.C;
+
+    uint4 wqf[NKT][2][2];                              // Wq rows d = tm*16+lp of this head (A operand)
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+                wqf[kt][ch][tm] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wq) +
+                    ((size_t)(h * 32 + tm * 16 + lp) * P.CPad + kt * M::KT) * M::ES + ch * 64 + q * 16);
+    f32x4 cf[2][2];                                    // ctx^T[e = et*16+lp][d = dt*16+4q..+3] (A operand of mma16)
+    {
+        const char* ct = reinterpret_cast<const char*>(P.ctxT) + (size_t)(n * P.heads + h) * 32 * 32 * M::ES;
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) cf[et][dt] = M::load_w4(ct + ((size_t)(et * 16 + lp) * 32 + dt * 16 + 4 * q) * M::ES);
+    }
+    // to_out tiles of this wave
+    const int cot0 = (TNO == 4) ? h * TMO : (h & 3);   // first output-channel tile
+    const int tn0 = (TNO == 4) ? 0 : 2 * (h >> 2);     // first pixel tile
+    const char* wo = reinterpret_cast<const char*>(P.wo);
+    uint4 wof[WO_RES ? TMO : 1][WO_RES ? NCHO : 1];
+    if (WO_RES) {
+#pragma unroll
+        for (int tmo = 0; tmo < TMO; ++tmo)
+#pragma unroll
+            for (int ch = 0; ch < NCHO; ++ch)
+                wof[tmo][ch] = *reinterpret_cast<const uint4*>(wo + (size_t)((cot0 + tmo) * 16 + lp) * HD * M::ES + ch * 64 + q * 16);
+    }
+
+    T t;
+    t.fetch(xf, chunk * R, P.N, P.C, tid);
+    t.put(smem, tid);
+    __syncthreads();
+    for (int sub = 0; sub < P.nsub; ++sub) {
+        const int r0 = chunk * R + sub * 64;
+        if (r0 >= P.N) break;
+        const char* xs = smem + (sub & 1) * T::BUF;
+        const bool more = (sub + 1 < P.nsub) && (r0 + 64 < P.N);
+        if (more) t.fetch(xf, r0 + 64, P.N, P.C, tid);
+        // q[d, n] of this head: lane (lp, q) = (pixel lp, channels 4q+r)
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                uint4 xb[4];
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) xb[tn] = *reinterpret_cast<const uint4*>(xs + kt * T::PLANE + (tn * 16 + lp) * RS + ch * 64 + q * 16);
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) M::mma(acc[tm][tn], wqf[kt][ch][tm], xb[tn]);
+            }
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {               // softmax over the 32 channels of the head, per pixel
+            float mx = -1e30f;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[tm][tn][r]);
+            mx = max_q(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { acc[tm][tn][r] = __expf(acc[tm][tn][r] - mx); sum += acc[tm][tn][r]; }
+            const float inv = 1.0f / reduce_q(sum);
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[tm][tn][r] *= inv;
+        }
+        // out[e, n] = sum_d ctx^T[e, d] q[d, n]  ->  os[n][h*32 + e]
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int et = 0; et < 2; ++et) {
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) M::mma16(o, cf[et][dt], acc[dt][tn]);
+                M::store4(os + (tn * 16 + lp) * RSO, h * 32 + et * 16 + 4 * q, make_float4(o[0], o[1], o[2], o[3]));
+            }
+        __syncthreads();
+        // to_out + residual
+        f32x4 oacc[TMO][TNO];
+#pragma unroll
+        for (int i = 0; i < TMO; ++i)
+#pragma unroll
+            for (int j = 0; j < TNO; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < NCHO; ++ch) {
+            uint4 bf[TNO];
+#pragma unroll
+            for (int tn = 0; tn < TNO; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(os + ((tn0 + tn) * 16 + lp) * RSO + ch * 64 + q * 16);
+#pragma unroll
+            for (int tmo = 0; tmo < TMO; ++tmo) {
+                uint4 a;
+                if (WO_RES) a = wof[tmo][ch];
+                else a = *reinterpret_cast<const uint4*>(wo + (size_t)((cot0 + tmo) * 16 + lp) * HD * M::ES + ch * 64 + q * 16);
+#pragma unroll
+                for (int tn = 0; tn < TNO; ++tn) M::mma(oacc[tmo][tn], a, bf[tn]);
+            }
+        }
+#pragma unroll
+        for (int tmo = 0; tmo < TMO; ++tmo) {
+            const int co = (cot0 + tmo) * 16 + 4 * q;
+#pragma unroll
+            for (int tn = 0; tn < TNO; ++tn) {
+                const int row = r0 + (tn0 + tn) * 16 + lp;
+                if (row >= P.N) continue;
+                const float4 xr = *reinterpret_cast<const float4*>(xf + (size_t)row * P.C + co);
+                *reinterpret_cast<float4*>(yf + (size_t)row * P.C + co) =
+                    make_float4(oacc[tmo][tn][0] + xr.x, oacc[tmo][tn][1] + xr.y, oacc[tmo][tn][2] + xr.z, oacc[tmo][tn][3] + xr.w);
+            }
+        }
+        if (more) t.put(smem + ((sub + 1) & 1) * T::BUF, tid);
+        __syncthreads();
+    }
+}
+
 // ---- host side -----------------------------------------------------------------------------------------
 
 void sla_plan(int N, int& nsub, int& nchunk) {
@@ -391,6 +692,25 @@ static hipError_t launch_sla_out_t(const SlaArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int MODE, int NKT, int TMO, int TNO>
+static hipError_t launch_sla8_t(const SlaArgs& a, hipStream_t st) {
+    using M = Mma<MODE>;
+    using T = SlaTile<MODE, NKT>;
+    const size_t lds_ctx = 2 * (size_t)T::BUF;
+    const size_t lds_out = lds_ctx + (size_t)64 * (256 * M::ES + 16);
+    auto kc = sla_ctx8_kernel<MODE, NKT>;
+    auto ko = sla_out8_kernel<MODE, NKT, TMO, TNO>;
+    hipError_t e;
+    if (lds_ctx > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ctx)) != hipSuccess) return e;
+    if (lds_out > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(ko), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_out)) != hipSuccess) return e;
+    hipLaunchKernelGGL(kc, dim3(a.NF * a.nchunk), dim3(512), lds_ctx, st, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(sla_combine_kernel<MODE>, dim3(a.NF * a.heads), dim3(256), 0, st, a.part, a.ctxT, a.nchunk, a.heads);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(ko, dim3(a.NF * a.nchunk), dim3(512), lds_out, st, a);
+    return hipGetLastError();
+}
+
 template <int MODE>
 static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
     using M = Mma<MODE>;
@@ -400,8 +720,15 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
     const size_t part_bytes = (((size_t)a.NF * a.nchunk * a.heads * SLA_PART * 4) + 255) / 256 * 256;
     a.part = reinterpret_cast<float*>(a.workspace);
     a.ctxT = reinterpret_cast<char*>(a.workspace) + part_bytes;
+    static const bool generic_only = getenv("VDX_SLA_GENERIC") != nullptr;
+    const int nkt = a.CPad / M::KT;
+    if (a.heads == 8 && a.C % 64 == 0 && !generic_only) {     // one wave per head; x tile double-buffered in LDS
+        if (nkt == 1 && a.C == 64) return launch_sla8_t<MODE, 1, 1, 2>(a, st);
+        if (nkt == 2 && a.C == 64) return launch_sla8_t<MODE, 2, 1, 2>(a, st);
+        if (nkt == 2 && a.C == 128) return launch_sla8_t<MODE, 2, 1, 4>(a, st);
+    }
     const size_t lds1 = 1024 + (size_t)128 * ROW_STRIDE + (size_t)64 * RSE;
-    hipLaunchKernelGGL(sla_ctx_kernel<MODE>, dim3(a.NF * a.nchunk, a.heads), dim3(256), lds1, st, a);
+    hipLaunchKernelGGL(sla_ctx_kernel<MODE>, dim3(((a.NF * a.nchunk + 7) / 8) * 8 * a.heads), dim3(256), lds1, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sla_combine_kernel<MODE>, dim3(a.NF * a.heads), dim3(256), 0, st, a.part, a.ctxT, a.nchunk, a.heads);
