@@ -16,6 +16,7 @@
 #include "vdx_common.h"
 #include "vdx_internal.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace vdx {
 
@@ -395,6 +396,217 @@ __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
     }
 }
 
+// One wave per head (heads == 8, sequences of <= 16 tokens, C small enough for register-resident weights): the layout
+// used for the temporal attention of the large levels.  A workgroup walks `nsub` sub-tiles of 4 sequences; wave h keeps
+// head h's q/k/v projection rows in registers as MFMA fragments for the whole walk, the fp32 x sub-tile is fetched once
+// for all heads (registers one sub-tile ahead -> LDS ring of 2), scores / softmax / PV stay in registers exactly as in
+// attention_reg_kernel, the heads meet in LDS (os[64 rows][256]) and the out-projection is split over the 8 waves by
+// (output-channel tile, sequence).  Global I/O is whole 16-byte pieces in (token, sequence, channel) order: one wave
+// instruction covers the contiguous run of 4 adjacent sequences, the output tile goes through LDS (ys) to be stored the
+// same way, and the fetched fp32 tile stays in registers as the residual.  Two barriers per sub-tile.
+// The kernel is vector-issue bound, so the per-sequence VALU work is kept minimal: biases are the accumulators' initial
+// values, 1/sqrt(d) is folded into the exponent, the key mask exists only for L < 16, cross-row reductions are permlane
+// swaps, and every address is (uniform base of the sub-tile) + (per-thread constant).  Host guarantees inner % 4 == 0 and
+// nseq % 4 == 0 (the 4 sequences of a sub-tile share their outer index) and 32-bit per-thread offsets.
+template <int MODE, int NKT, int TMO, int TNO>
+__global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, const int nsub) {
+    using M = Mma<MODE>;
+    constexpr int KT = M::KT, KC = M::KC, RS = ROW_STRIDE, D = 32, HD = 256;
+    constexpr int APIECES = KT / 4;
+    constexpr int XP = 64 * APIECES * NKT / 512;
+    constexpr int PLANE = 64 * RS, BUF = NKT * PLANE;
+    constexpr int RSO = HD * M::ES + 16;
+    constexpr int NCHO = HD / KC;
+    constexpr int CT = NKT * KT;                                      // channels held by the tile (== C)
+    constexpr int RSY = CT * 4 + 16;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // xs[2][NKT][64][RS] | os[64][RSO] | ys[64][RSY] (fp32)
+    char* os = smem + 2 * BUF;
+    char* ys = os + 64 * RSO;
+    const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+
+    // per-thread constants of its XP pieces: global element offset inside the sub-tile, LDS offsets (x tile, y tile)
+    unsigned goff[XP];
+    int xoff[XP], yoff[XP];
+    bool pvalid[XP];
+#pragma unroll
+    for (int u = 0; u < XP; ++u) {
+        const int i = tid + 512 * u;
+        const int kt = i / (64 * APIECES), rem = i % (64 * APIECES);
+        const int ridx = rem / APIECES, pc = rem % APIECES;          // ridx = token * 4 + sequence: 4 adjacent sequences =
+        const int sl = ridx & 3, tok = ridx >> 2, c = kt * KT + pc * 4;   // one contiguous run per token
+        goff[u] = (unsigned)(sl * P.inner_stride + tok * P.tok_stride + c);
+        xoff[u] = kt * PLANE + (sl * 16 + tok) * RS + pc * 4 * M::ES;   // LDS row = sequence * 16 + token
+        yoff[u] = (sl * 16 + tok) * RSY + c * 4;
+        pvalid[u] = tok < P.L && c < P.C;
+    }
+    auto tile_base = [&](long sg0) -> long {                         // workgroup-uniform: scalar unit
+        const unsigned inner = (unsigned)P.inner;
+        return (long)((unsigned)sg0 / inner) * P.outer_stride + (long)((unsigned)sg0 % inner) * P.inner_stride;
+    };
+    float4 xpre[XP];
+    auto fetch = [&](long sg0) {
+        const float* xb = P.x + tile_base(sg0);
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            xpre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pvalid[u]) xpre[u] = *reinterpret_cast<const float4*>(xb + goff[u]);
+        }
+    };
+    auto put = [&](char* xs) {
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            if (MODE == MODE_F32) *reinterpret_cast<float4*>(xs + xoff[u]) = xpre[u];
+            else *reinterpret_cast<uint2*>(xs + xoff[u]) = make_uint2(pack_bf16x2(xpre[u].x, xpre[u].y), pack_bf16x2(xpre[u].z, xpre[u].w));
+        }
+    };
+
+    // head h's projection rows: part 0 = q, 1 = k (A operands: rows d), 2 = v (B operand: cols d)
+    uint4 wf[NKT][2][3][2];
+    {
+        const char* wq = reinterpret_cast<const char*>(P.wqkv);
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int part = 0; part < 3; ++part)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        wf[kt][ch][part][t] = *reinterpret_cast<const uint4*>(
+                            wq + ((size_t)(part * HD + h * D + t * 16 + lp) * P.CPad + kt * KT) * M::ES + ch * 64 + q * 16);
+    }
+    f32x4 bq[2], bk[2], bv[2];                         // biases in accumulator layout = the accumulators' initial values
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float4 a = *reinterpret_cast<const float4*>(P.bqkv + h * D + t * 16 + 4 * q);
+        const float4 b = *reinterpret_cast<const float4*>(P.bqkv + HD + h * D + t * 16 + 4 * q);
+        const float c = P.bqkv[2 * HD + h * D + t * 16 + lp];
+        bq[t] = f32x4{a.x, a.y, a.z, a.w};
+        bk[t] = f32x4{b.x, b.y, b.z, b.w};
+        bv[t] = f32x4{c, c, c, c};
+    }
+    const float escale = P.scale * 1.44269504088896f;  // softmax(scale * s) = exp2((s - max s) * scale * log2 e) / sum
+    // out-projection tiles of this wave
+    const int cot0 = (TNO == 4) ? h * TMO : (h & 3);
+    const int tn0 = (TNO == 4) ? 0 : 2 * (h >> 2);
+    const char* wo = reinterpret_cast<const char*>(P.wo);
+    uint4 wof[TMO][NCHO];
+#pragma unroll
+    for (int tmo = 0; tmo < TMO; ++tmo)
+#pragma unroll
+        for (int ch = 0; ch < NCHO; ++ch)
+            wof[tmo][ch] = *reinterpret_cast<const uint4*>(wo + (size_t)((cot0 + tmo) * 16 + lp) * P.HDPad * M::ES + ch * 64 + q * 16);
+    f32x4 bo[TMO];
+#pragma unroll
+    for (int tmo = 0; tmo < TMO; ++tmo) {
+        const float4 b = *reinterpret_cast<const float4*>(P.bo + (cot0 + tmo) * 16 + 4 * q);
+        bo[tmo] = f32x4{b.x, b.y, b.z, b.w};
+    }
+    const bool masked = P.L < 16;
+
+    const long sg_first = (long)blockIdx.x * nsub * 4;
+    fetch(sg_first);
+    put(smem);
+    __syncthreads();
+    for (int sub = 0; sub < nsub; ++sub) {
+        const long sg0 = sg_first + (long)sub * 4;
+        if (sg0 >= P.nseq) break;                      // uniform across the workgroup
+        const char* xs = smem + (sub & 1) * BUF;
+        const bool more = (sub + 1 < nsub) && (sg0 + 4 < P.nseq);
+        float4 xcur[XP];                               // this sub-tile's fp32 rows = the residual of its output (no re-read)
+#pragma unroll
+        for (int u = 0; u < XP; ++u) xcur[u] = xpre[u];
+        if (more) fetch(sg0 + 4);
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) {               // one sequence = one 16-row tile
+            f32x4 aq[2], ak[2], av[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { aq[t] = bq[t]; ak[t] = bk[t]; av[t] = bv[t]; }
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const uint4 xf = *reinterpret_cast<const uint4*>(xs + kt * PLANE + (sl * 16 + lp) * RS + ch * 64 + q * 16);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        M::mma(aq[t], wf[kt][ch][0][t], xf);
+                        M::mma(ak[t], wf[kt][ch][1][t], xf);
+                        M::mma(av[t], xf, wf[kt][ch][2][t]);      // swapped: rows = tokens, cols = d
+                    }
+                }
+            f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};      // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
+            M::mma16(sc, ak[0], aq[0]);
+            M::mma16(sc, ak[1], aq[1]);
+            if (masked) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (4 * q + r >= P.L) sc[r] = -1e30f;
+            }
+            const float mx = max_q(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sc[r] = __builtin_amdgcn_exp2f((sc[r] - mx) * escale); sum += sc[r]; }
+            const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sc[r] *= inv;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {              // O^T[d, i] -> os[row i][h*32 + d]
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                M::mma16(o, av[t], sc);
+                M::store4(os + (sl * 16 + lp) * RSO, h * D + t * 16 + 4 * q, make_float4(o[0], o[1], o[2], o[3]));
+            }
+        }
+        __syncthreads();
+        f32x4 oacc[TMO][TNO];
+#pragma unroll
+        for (int i = 0; i < TMO; ++i)
+#pragma unroll
+            for (int j = 0; j < TNO; ++j) oacc[i][j] = bo[i];
+#pragma unroll
+        for (int ch = 0; ch < NCHO; ++ch) {
+            uint4 bf[TNO];
+#pragma unroll
+            for (int tn = 0; tn < TNO; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(os + ((tn0 + tn) * 16 + lp) * RSO + ch * 64 + q * 16);
+#pragma unroll
+            for (int tmo = 0; tmo < TMO; ++tmo)
+#pragma unroll
+                for (int tn = 0; tn < TNO; ++tn) M::mma(oacc[tmo][tn], wof[tmo][ch], bf[tn]);
+        }
+        // out tile -> ys, then every wave stores whole 16-byte pieces in fetch order: coalesced, + residual from registers
+#pragma unroll
+        for (int tmo = 0; tmo < TMO; ++tmo)
+#pragma unroll
+            for (int tn = 0; tn < TNO; ++tn)
+                *reinterpret_cast<f32x4*>(ys + ((tn0 + tn) * 16 + lp) * RSY + ((cot0 + tmo) * 16 + 4 * q) * 4) = oacc[tmo][tn];
+        if (more) put(smem + ((sub + 1) & 1) * BUF);
+        __syncthreads();
+        float* yb = P.y + tile_base(sg0);
+#pragma unroll
+        for (int u = 0; u < XP; ++u) {
+            if (!pvalid[u]) continue;
+            const float4 o4 = *reinterpret_cast<const float4*>(ys + yoff[u]);
+            *reinterpret_cast<float4*>(yb + goff[u]) = make_float4(o4.x + xcur[u].x, o4.y + xcur[u].y, o4.z + xcur[u].z, o4.w + xcur[u].w);
+        }
+    }
+}
+
+template <int MODE, int NKT, int TMO, int TNO>
+static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
+    using M = Mma<MODE>;
+    const size_t lds = 2 * (size_t)NKT * 64 * ROW_STRIDE + (size_t)64 * (256 * M::ES + 16) + (size_t)64 * (NKT * M::KT * 4 + 16);
+    auto kfn = attention_h8_kernel<MODE, NKT, TMO, TNO>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    const long subtiles = (a.nseq + 3) / 4;
+    const int nsub = (int)std::min<long>(8, std::max<long>(1, subtiles / 1024));
+    const long blocks = (subtiles + nsub - 1) / nsub;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, st, a, nsub);
+    return hipGetLastError();
+}
+
 template <int MODE, int TMA>
 static hipError_t launch_attn_reg_t(const AttnArgs& a, hipStream_t st) {
     const size_t lds = 512 + (size_t)(64 + 96) * ROW_STRIDE + (size_t)TMA * 16 * (32 * Mma<MODE>::ES + 16);
@@ -441,6 +653,15 @@ static hipError_t launch_attn_l(const AttnArgs& a, hipStream_t st) {
 template <int MODE>
 static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
     static const bool use_reg = getenv("VDX_ATTN_LDS") == nullptr;        // debugging switch: force the LDS-staged kernel
+    static const bool use_h8 = getenv("VDX_ATTN_NOH8") == nullptr;        // debugging switch: skip the one-wave-per-head kernel
+    const bool h8_ok = a.L <= 16 && a.heads == 8 && a.inner % 4 == 0 && a.nseq % 4 == 0 && a.nseq < (1L << 31) &&
+                       3 * a.inner_stride + 15 * a.tok_stride + a.C < (1L << 31);
+    if (h8_ok && use_reg && use_h8) {
+        const int nkt = a.CPad / Mma<MODE>::KT;
+        if (a.C == 64 && nkt == 1) return launch_attn_h8_t<MODE, 1, 1, 2>(a, st);
+        if (a.C == 64 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 2>(a, st);
+        if (a.C == 128 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 4>(a, st);
+    }
     if (a.L <= 16 && use_reg) return launch_attn_reg<MODE>(a, st);
     if (a.L <= 16) return launch_attn_l<MODE, 16>(a, st);
     if (a.L <= 32) return launch_attn_l<MODE, 32>(a, st);

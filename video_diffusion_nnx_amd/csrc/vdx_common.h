@@ -119,16 +119,21 @@ __device__ __forceinline__ float reduce16(float v) {
     v += __shfl_xor(v, 8);
     return v;
 }
-// sum over the 4 lanes that share (lane & 15)
+// reductions over the 4 lanes that share (lane & 15), result in all of them.  v_permlane32_swap exchanges the upper half
+// of its first operand with the lower half of its second, v_permlane16_swap the odd 16-lane rows of the first with the
+// even rows of the second: with both operands = v the two results are v[l] and v[l ^ 32] (resp. ^ 16) arranged so that
+// one VALU op combines them -- no ds_bpermute round trip through the LDS crossbar.
 __device__ __forceinline__ float reduce_q(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float max_q(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+    const auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float max16(float v) {
     v = fmaxf(v, __shfl_xor(v, 1));
