@@ -401,6 +401,45 @@ struct SlaTile {
     }
 };
 
+// online-softmax step of sla_ctx8 over one 32-pixel half sub-tile: channel d = dt*16 + lp lives in lane lp, its pixels in
+// (tn, q, r).  e = exp(a - m) is evaluated as exp2(a * log2e - m * log2e): one FMA + one v_exp per element.
+// FULL = every pixel of the sub-tile exists (no masks); else `nleft` = pixels left counting from this lane's (tn = 0, r = 0).
+template <bool FULL>
+__device__ __forceinline__ void ctx8_softmax_step(f32x4 (&acc)[2][4], float (&m_run)[2], float (&s_run)[2], f32x4 (&cacc)[2][2], int nleft) {
+    constexpr float L2E = 1.44269504088896f;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        if (!FULL) {
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (tn * 16 + r >= nleft) acc[tn][dt][r] = -1e30f;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(acc[0][dt][0], acc[0][dt][1]), fmaxf(acc[0][dt][2], acc[0][dt][3])),
+                         fmaxf(fmaxf(acc[1][dt][0], acc[1][dt][1]), fmaxf(acc[1][dt][2], acc[1][dt][3])));
+        mx = max_q(mx);
+        const float mn = fmaxf(m_run[dt], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[dt] - mn) * L2E);
+        m_run[dt] = mn;
+        const float nb = -mn * L2E;
+        float ssum = 0.f;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float e = __builtin_amdgcn_exp2f(__builtin_fmaf(acc[tn][dt][r], L2E, nb));
+                if (!FULL) e = (tn * 16 + r >= nleft) ? 0.f : e;
+                acc[tn][dt][r] = e;
+                ssum += e;
+            }
+        s_run[dt] = s_run[dt] * alpha + reduce_q(ssum);
+#pragma unroll
+        for (int et = 0; et < 2; ++et)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cacc[et][dt][r] *= alpha;
+    }
+}
+
 template <int MODE, int NKT>
 __global__ __launch_bounds__(512) void sla_ctx8_kernel(const SlaArgs P) {
     using M = Mma<MODE>;
@@ -459,37 +498,8 @@ __global__ __launch_bounds__(512) void sla_ctx8_kernel(const SlaArgs P) {
 #pragma unroll
                         for (int tm = 0; tm < 4; ++tm) M::mma(acc[tn][tm], xa[tn], wf[kt][ch][tm]);
                 }
-            bool valid[2][4];
-#pragma unroll
-            for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) valid[tn][r] = (r0 + (hf * 2 + tn) * 16 + 4 * q + r) < P.N;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {           // softmax over pixels of channel d = dt*16+lp
-                float mx = -1e30f;
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, valid[tn][r] ? acc[tn][dt][r] : -1e30f);
-                mx = max_q(mx);
-                const float mn = fmaxf(m_run[dt], mx);
-                const float alpha = __expf(m_run[dt] - mn);
-                m_run[dt] = mn;
-                float ssum = 0.f;
-#pragma unroll
-                for (int tn = 0; tn < 2; ++tn)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = valid[tn][r] ? __expf(acc[tn][dt][r] - mn) : 0.f;
-                        acc[tn][dt][r] = e;
-                        ssum += e;
-                    }
-                s_run[dt] = s_run[dt] * alpha + reduce_q(ssum);
-#pragma unroll
-                for (int et = 0; et < 2; ++et)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) cacc[et][dt][r] *= alpha;
-            }
+            if (r0 + 64 <= P.N) ctx8_softmax_step<true>(acc, m_run, s_run, cacc, 0);                  // uniform branch
+            else ctx8_softmax_step<false>(acc, m_run, s_run, cacc, P.N - (r0 + hf * 32 + 4 * q));
             // ctx^T[e, d] += sum_n v[e, n] e_k[d, n]: both operands are the accumulators above (k = pixel 4q+r);
             // invalid pixels contribute v = 0 (x rows zero-filled, no bias) and e_k = 0
 #pragma unroll
