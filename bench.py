@@ -150,6 +150,8 @@ def main():
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--frames', type=int, default=16)
     ap.add_argument('--size', type=int, default=64)
+    ap.add_argument('--act-storage', default=os.environ.get('VDX_BENCH_ACT', 'auto'), choices=['auto', 'f32', 'bf16'],
+                    help='storage of the inter-kernel activations (auto: bf16 in bf16 mode, as GaussianDiffusion.sample does)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     args = ap.parse_args()
@@ -173,6 +175,9 @@ def main():
     unet = Unet3D(dim=args.dim, rngs=0, channels=1, mode=args.mode, device=dev)
     gd = GaussianDiffusion(unet, image_size=S, num_frames=Fr, channels=1, timesteps=T_STEPS, loss_type='l2')
     h = unet.handle(Fr, S)
+    act = args.act_storage if args.act_storage != 'auto' else ('bf16' if args.mode == 'bf16' else 'f32')
+    unet.act_bf16 = (act == 'bf16')
+    unet.apply_activation_storage(h)
     ws = unet.workspace(B, Fr, S)
     stream = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(stream):
@@ -214,7 +219,7 @@ def main():
         'config': {'workload': f'config_v2_2 (north-star shape): Unet3D dim={args.dim} C=1, {Fr}f x {S}x{S}, DDPM T={T_STEPS} p_sample_loop '
                                f'(UNet forward + p_sample per step, hipGraph replay); value = n_gpus*B*F/(T*s_per_step)',
                    'batch_per_gpu': B, 'timesteps': T_STEPS, 'parallelism': f'dp{world} (independent samples, no collective)',
-                   'mfma_operands': args.mode, 'storage': 'fp32'},
+                   'mfma_operands': args.mode, 'storage': f'weights fp32 master, activations {act}, fp32 accumulate'},
     }
     log(f'timed region done: {ms_per_step:.3f} ms/step')
     if rank == 0 and not args.no_roofline:

@@ -147,6 +147,13 @@ typedef struct vdx_handle vdx_handle;
 int vdx_create(const vdx_config* cfg, vdx_handle** out);
 void vdx_destroy(vdx_handle* h);
 
+/* Activation storage of vdx_unet_forward / vdx_p_sample_loop.  0 (default): every inter-kernel activation is fp32 in the
+ * workspace (required by vdx_unet_backward, and what vdx_slot_info describes).  1 (VDX_MODE_BF16 handles only): they are
+ * stored as bf16 -- half the HBM traffic of the bandwidth-bound levels; arithmetic stays fp32-accumulate.  The reference
+ * has no such knob (XLA picks its own buffer types); this is the "bf16" of BASELINE.json's sampling configuration. */
+int vdx_set_activation_storage(vdx_handle* h, int bf16);
+int vdx_get_activation_storage(const vdx_handle* h);
+
 /* Flat fp32 parameter buffer layout (names = nnx state-tree paths, shapes = Flax shapes). */
 int vdx_param_count(const vdx_handle* h);
 long vdx_param_total(const vdx_handle* h);                       /* floats in the flat buffer */

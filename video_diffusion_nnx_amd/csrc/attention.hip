@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs P) {
             const int c = kt * KT + pc * 4;
             const long ro = rowoff[row];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ro >= 0 && c < P.C) v = *reinterpret_cast<const float4*>(P.x + ro + c);
+            if (ro >= 0 && c < P.C) v = load4_f32_or_bf16(P.x, (size_t)(ro + c), P.io_bf16);
             M::store4(xs + row * RS, pc * 4, v);
         }
     };
@@ -225,11 +225,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs P) {
         for (int tn = 0; tn < 4; ++tn) {
             const long ro = rowoff[tn * 16 + lp];
             if (ro < 0) continue;
-            const float4 xr = *reinterpret_cast<const float4*>(P.x + ro + co);
+            const float4 xr = load4_f32_or_bf16(P.x, (size_t)(ro + co), P.io_bf16);
             float4 v;
             v.x = oacc[tmo][tn][0] + bo.x + xr.x; v.y = oacc[tmo][tn][1] + bo.y + xr.y;
             v.z = oacc[tmo][tn][2] + bo.z + xr.z; v.w = oacc[tmo][tn][3] + bo.w + xr.w;
-            *reinterpret_cast<float4*>(P.y + ro + co) = v;
+            store4_f32_or_bf16(P.y, (size_t)(ro + co), v, P.io_bf16);
         }
     }
 }
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
             const int c = kt * KT + pc * 4;
             const long ro = rowoff[row];
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ro >= 0 && c < P.C) v = *reinterpret_cast<const float4*>(P.x + ro + c);
+            if (ro >= 0 && c < P.C) v = load4_f32_or_bf16(P.x, (size_t)(ro + c), P.io_bf16);
             M::store4(xs + row * RS, pc * 4, v);
         }
     };
@@ -388,11 +388,11 @@ __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
         if (co >= P.C || ro < 0) continue;
         const float4 bo = *reinterpret_cast<const float4*>(P.bo + co);
         float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(P.dbg & 4)) xr = *reinterpret_cast<const float4*>(P.x + ro + co);
+        if (!(P.dbg & 4)) xr = load4_f32_or_bf16(P.x, (size_t)(ro + co), P.io_bf16);
         float4 v;
         v.x = oacc[tm][0] + bo.x + xr.x; v.y = oacc[tm][1] + bo.y + xr.y;
         v.z = oacc[tm][2] + bo.z + xr.z; v.w = oacc[tm][3] + bo.w + xr.w;
-        if (!(P.dbg & 8)) *reinterpret_cast<float4*>(P.y + ro + co) = v;
+        if (!(P.dbg & 8)) store4_f32_or_bf16(P.y, (size_t)(ro + co), v, P.io_bf16);
     }
 }
 
@@ -447,11 +447,11 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     };
     float4 xpre[XP];
     auto fetch = [&](long sg0) {
-        const float* xb = P.x + tile_base(sg0);
+        const size_t xb = (size_t)tile_base(sg0);
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             xpre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pvalid[u]) xpre[u] = *reinterpret_cast<const float4*>(xb + goff[u]);
+            if (pvalid[u]) xpre[u] = load4_f32_or_bf16(P.x, xb + goff[u], P.io_bf16);
         }
     };
     auto put = [&](char* xs) {
@@ -581,12 +581,12 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
                 *reinterpret_cast<f32x4*>(ys + ((tn0 + tn) * 16 + lp) * RSY + ((cot0 + tmo) * 16 + 4 * q) * 4) = oacc[tmo][tn];
         if (more) put(smem + ((sub + 1) & 1) * BUF);
         __syncthreads();
-        float* yb = P.y + tile_base(sg0);
+        const size_t yb = (size_t)tile_base(sg0);
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             if (!pvalid[u]) continue;
             const float4 o4 = *reinterpret_cast<const float4*>(ys + yoff[u]);
-            *reinterpret_cast<float4*>(yb + goff[u]) = make_float4(o4.x + xcur[u].x, o4.y + xcur[u].y, o4.z + xcur[u].z, o4.w + xcur[u].w);
+            store4_f32_or_bf16(P.y, yb + goff[u], make_float4(o4.x + xcur[u].x, o4.y + xcur[u].y, o4.z + xcur[u].z, o4.w + xcur[u].w), P.io_bf16);
         }
     }
 }

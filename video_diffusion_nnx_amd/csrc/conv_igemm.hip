@@ -17,6 +17,7 @@
 // a 2-deep register->LDS ring.  Accumulators: lane (r,q) holds channels 4q..4q+3 of pixel r (vdx_common.h).
 #include "vdx_common.h"
 #include "vdx_internal.h"
+#include <stdlib.h>
 
 namespace vdx {
 
@@ -25,16 +26,17 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned OOB = 0xFFFFFFF0u;      // buffer-load offset beyond num_records: the hardware returns zeros
 
 // TN = 16-pixel tiles per wave (4: 64 pixels, 2: 32 pixels).  Workgroup tile = BC channels x BM pixels.
-template <int MODE, int BC, int TN>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
+template <int MODE, int BC, int TN, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
     using M = Mma<MODE>;
     constexpr int KT = M::KT;
     constexpr int RS = ROW_STRIDE;
     constexpr int WAVES_C = BC / 64;
-    constexpr int WAVES_P = 4 / WAVES_C;
+    constexpr int WAVES_P = NW / WAVES_C;
+    constexpr int NT = 64 * NW;                     // threads per workgroup
     constexpr int TM = 4;
     constexpr int APIECES = KT / 4;                 // float4 pieces per staged pixel row
-    constexpr int WREGS = BC * 8 / 256;             // 16-byte weight pieces per thread per tap
+    constexpr int WREGS = BC * 8 / NT;              // 16-byte weight pieces per thread per tap
     constexpr int AU = 4;                           // halo-tile loads in flight per thread (one or two batches per tile)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
     char* As = smem + off; off += (size_t)HPX * RS;
     char* Ws = smem + off;                                                          // [2][BC rows]
 
-    for (int i = tid; i < 2 * BC; i += 256) chs[i] = 0.f;
-    for (int hp = tid; hp < HPX; hp += 256) {
+    for (int i = tid; i < 2 * BC; i += NT) chs[i] = 0.f;
+    for (int hp = tid; hp < HPX; hp += NT) {
         const int patch = hp / (IH * IW);
         const int r = hp - patch * (IH * IW);
         const int iy = r / IW, ix = r - iy * IW;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
             gmean[2 * tid] = m; gmean[2 * tid + 1] = rs;
         }
         __syncthreads();
-        for (int c = tid; c < P.CinPad; c += 256) {
+        for (int c = tid; c < P.CinPad; c += NT) {
             float a = 0.f, d = 0.f;
             if (c < Cin) {
                 const int g = c / (Cin / P.groups);
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
     int wdst[WREGS];
 #pragma unroll
     for (int k = 0; k < WREGS; ++k) {
-        const int row = (tid >> 3) + 32 * k;
+        const int row = (tid >> 3) + (NT / 8) * k;
         const int co = min(c0 + row, P.Cout - 1);     // rows past Cout re-read the last row; their outputs are never stored
         wvoff[k] = (unsigned)((co + P.wrow0) * P.CinPad) * M::ES + (tid & 7) * 16;
         wdst[k] = row * RS + (tid & 7) * 16;
@@ -162,15 +164,61 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
 
     // ---- main loop: K tiles of cin x taps --------------------------------------------------------
     const int total = HPX * APIECES;
+    const bool in16 = P.x0_bf16 && (!P.C1 || P.x1_bf16) && (P.C0 % 8 == 0) && (P.C1 % 8 == 0);
     int buf = 0;
     wload(0, 0, 0);
     for (int cc = 0; cc < nchunks; ++cc) {
         if (cc) __syncthreads();                     // every wave is done reading the previous halo tile
-        for (int i0 = tid; i0 < total; i0 += 256 * AU) {
+        if (MODE == MODE_BF16 && in16) {
+            // every input tensor is bf16: 16-byte pieces of 8 channels, half the loads / address math / LDS writes, and a
+            // plain copy into the bf16 tile when there is no prologue
+            constexpr int BP = KT / 8;
+            const int total8 = HPX * BP;
+            for (int i0 = tid; i0 < total8; i0 += NT * AU) {
+                u32x4 v[AU];
+#pragma unroll
+                for (int u = 0; u < AU; ++u) {
+                    const int i = i0 + NT * u;
+                    const int hp = i / BP, pc = i % BP;
+                    const int c = cc * KT + pc * 8;
+                    const int pix = (i < total8) ? hp_pix[hp] : -1;
+                    const unsigned o0 = (pix >= 0 && c < P.C0) ? (unsigned)(pix * P.C0 + c) * 2u : OOB;
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0);
+                    if (P.C1) {
+                        const unsigned o1 = (pix >= 0 && c >= P.C0 && c < Cin) ? (unsigned)(pix * P.C1 + (c - P.C0)) * 2u : OOB;
+                        v[u] |= __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < AU; ++u) {
+                    const int i = i0 + NT * u;
+                    if (i < total8) {
+                        const int hp = i / BP, pc = i % BP;
+                        if (P.pro) {
+                            const int c = cc * KT + pc * 8;
+                            const bool ok = hp_pix[hp] >= 0 && c < Cin;       // zero padding stays zero AFTER the activation
+                            const unsigned w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                            unsigned o4[4];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float2 a = *reinterpret_cast<const float2*>(coefA + c + 2 * k);
+                                const float2 d = *reinterpret_cast<const float2*>(coefD + c + 2 * k);
+                                const float lo = silu_f(fmaf(__uint_as_float(w4[k] << 16), a.x, d.x));
+                                const float hi = silu_f(fmaf(__uint_as_float(w4[k] & 0xFFFF0000u), a.y, d.y));
+                                o4[k] = ok ? pack_bf16x2(lo, hi) : 0u;
+                            }
+                            v[u] = u32x4{o4[0], o4[1], o4[2], o4[3]};
+                        }
+                        *reinterpret_cast<u32x4*>(As + hp * RS + pc * 16) = v[u];
+                    }
+                }
+            }
+        } else
+        for (int i0 = tid; i0 < total; i0 += NT * AU) {
             u32x4 v[AU];
 #pragma unroll
             for (int u = 0; u < AU; ++u) {
-                const int i = i0 + 256 * u;
+                const int i = i0 + NT * u;
                 const int hp = i / APIECES, pc = i % APIECES;
                 const int c = cc * KT + pc * 4;
                 const int pix = (i < total) ? hp_pix[hp] : -1;
@@ -183,13 +231,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs P) {
                     v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0);
                 }
                 if (P.C1) {
-                    const unsigned o1 = (pix >= 0 && c >= P.C0 && c < Cin) ? (unsigned)(pix * P.C1 + (c - P.C0)) * 4u : OOB;
-                    v[u] |= __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
+                    if (P.x1_bf16) {
+                        const unsigned o1 = (pix >= 0 && c >= P.C0 && c < Cin) ? (unsigned)(pix * P.C1 + (c - P.C0)) * 2u : OOB;
+                        const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rs1, o1, 0, 0);
+                        v[u] |= u32x4{h2.x << 16, h2.x & 0xFFFF0000u, h2.y << 16, h2.y & 0xFFFF0000u};
+                    } else {
+                        const unsigned o1 = (pix >= 0 && c >= P.C0 && c < Cin) ? (unsigned)(pix * P.C1 + (c - P.C0)) * 4u : OOB;
+                        v[u] |= __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < AU; ++u) {
-                const int i = i0 + 256 * u;
+                const int i = i0 + NT * u;
                 if (i < total) {
                     const int hp = i / APIECES, pc = i % APIECES;
                     float4 f = make_float4(__uint_as_float(v[u].x), __uint_as_float(v[u].y), __uint_as_float(v[u].z), __uint_as_float(v[u].w));
@@ -375,11 +429,12 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     const int ES = mode == MODE_F32 ? 4 : 2;
     const size_t npix = (size_t)a.NF * a.H * a.W;
     if (a.wrows <= 0) { a.wrows = a.Cout; a.wrow0 = 0; }
-    const size_t b0 = npix * a.C0 * (a.x0_bf16 ? 2 : 4), b1 = npix * a.C1 * 4, bw = (size_t)(a.kind ? 16 : a.kh * a.kw) * a.wrows * a.CinPad * ES;
+    const size_t b0 = npix * a.C0 * (a.x0_bf16 ? 2 : 4), b1 = npix * a.C1 * (a.x1_bf16 ? 2 : 4), bw = (size_t)(a.kind ? 16 : a.kh * a.kw) * a.wrows * a.CinPad * ES;
     if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
     a.x0_bytes = (unsigned)b0; a.x1_bytes = (unsigned)b1; a.w_bytes = (unsigned)bw;
     // variant: 64-channel tiles take 256 pixels per workgroup (stride 1) so every wave owns a 64x64 tile
     const int BC = a.Cout <= 64 ? 64 : 128;
+    static const int nw8 = getenv("VDX_CONV_NW8") ? atoi(getenv("VDX_CONV_NW8")) : 0;     // experiment: 8-wave workgroups, same tile
     const int TN = (BC == 64 && a.stride == 2) ? 2 : 4;
     const int BM = 16 * TN * (4 / (BC / 64));
     choose_patch(BM, a.NF, a.F, a.Ho, a.Wo, a.stride, K, a.PH, a.PW, a.NP);
@@ -393,12 +448,13 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     dim3 grid((a.NF / a.NP) * a.tiles_y * a.tiles_x, (a.Cout + BC - 1) / BC, a.kind ? 4 : 1);
 #define VDX_LAUNCH_CONV(MODE_, BC_, TN_)                                                                 \
     do {                                                                                                  \
-        auto kfn = conv_igemm_kernel<MODE_, BC_, TN_>;                                                    \
+        const bool w8 = nw8 && TN_ == 4;                                                                  \
+        auto kfn = w8 ? conv_igemm_kernel<MODE_, BC_, 2, 8> : conv_igemm_kernel<MODE_, BC_, TN_, 4>;      \
         if (lds > 64 * 1024) {                                                                            \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                \
         }                                                                                                 \
-        hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a);                                             \
+        hipLaunchKernelGGL(kfn, grid, dim3(w8 ? 512 : 256), lds, st, a);                                             \
     } while (0)
     if (mode == MODE_F32) {
         if (BC == 128) VDX_LAUNCH_CONV(MODE_F32, 128, 4); else if (TN == 4) VDX_LAUNCH_CONV(MODE_F32, 64, 4); else VDX_LAUNCH_CONV(MODE_F32, 64, 2);

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void resblock_tail_kernel(TailArgs P) {
             const int c = (v * LPP + sub) * 4;
             r[v] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (c < C) {
-                r[v] = *reinterpret_cast<const float4*>(P.r + base + c);
+                r[v] = load4_f32_or_bf16(P.r, base + c, P.r_bf16);
                 s += r[v].x + r[v].y + r[v].z + r[v].w;
                 ss += r[v].x * r[v].x + r[v].y * r[v].y + r[v].z * r[v].z + r[v].w * r[v].w;
             }
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void resblock_tail_kernel(TailArgs P) {
                 o.y = silu_f(fmaf(y.y, a.y, d.y)) + fmaf((r[v].y - mean) * rstd, lg.y, lb.y);
                 o.z = silu_f(fmaf(y.z, a.z, d.z)) + fmaf((r[v].z - mean) * rstd, lg.z, lb.z);
                 o.w = silu_f(fmaf(y.w, a.w, d.w)) + fmaf((r[v].w - mean) * rstd, lg.w, lb.w);
-                *reinterpret_cast<float4*>(P.out + base + c) = o;
+                store4_f32_or_bf16(P.out, base + c, o, P.out_bf16);
             }
         }
     }
@@ -100,7 +100,7 @@ hipError_t launch_resblock_tail(TailArgs a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void init_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y,
-                                                        int B, int Cin, int F, int H, int W, int Cout, int K) {
+                                                        int B, int Cin, int F, int H, int W, int Cout, int K, int y_bf16) {
     extern __shared__ float tile[];                       // [Cin][16+K-1][16+K-1]
     const int pad = K / 2, TW = 16 + K - 1;
     const int tx = blockIdx.x % ((W + 15) / 16), ty = blockIdx.x / ((W + 15) / 16);
@@ -129,23 +129,26 @@ __global__ __launch_bounds__(256) void init_conv_kernel(const float* __restrict_
             }
     const int oy = ty * 16 + py, ox = tx * 16 + px;
     if (oy < H && ox < W) {
-        float* o = y + ((((size_t)b * F + f) * H + oy) * W + ox) * Cout + co0;
+        const size_t ob = ((((size_t)b * F + f) * H + oy) * W + ox) * Cout + co0;
         if (co0 + 16 <= Cout) {
 #pragma unroll
             for (int j = 0; j < 16; j += 4)
-                *reinterpret_cast<float4*>(o + j) = make_float4(acc[j] + bias[co0 + j], acc[j + 1] + bias[co0 + j + 1],
-                                                                 acc[j + 2] + bias[co0 + j + 2], acc[j + 3] + bias[co0 + j + 3]);
+                store4_f32_or_bf16(y, ob + j, make_float4(acc[j] + bias[co0 + j], acc[j + 1] + bias[co0 + j + 1],
+                                                          acc[j + 2] + bias[co0 + j + 2], acc[j + 3] + bias[co0 + j + 3]), y_bf16);
         } else {
-            for (int j = 0; j < 16 && co0 + j < Cout; ++j) o[j] = acc[j] + bias[co0 + j];
+            for (int j = 0; j < 16 && co0 + j < Cout; ++j) {
+                if (y_bf16) reinterpret_cast<__bf16*>(y)[ob + j] = (__bf16)(acc[j] + bias[co0 + j]);
+                else y[ob + j] = acc[j] + bias[co0 + j];
+            }
         }
     }
 }
 
 hipError_t launch_init_conv(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int F, int H, int W,
-                            int Cout, int K, hipStream_t st) {
+                            int Cout, int K, int y_bf16, hipStream_t st) {
     const int TW = 16 + K - 1;
     dim3 grid(((W + 15) / 16) * ((H + 15) / 16), B * F, (Cout + 15) / 16);
-    hipLaunchKernelGGL(init_conv_kernel, grid, dim3(256), (size_t)Cin * TW * TW * 4, st, x, w, bias, y, B, Cin, F, H, W, Cout, K);
+    hipLaunchKernelGGL(init_conv_kernel, grid, dim3(256), (size_t)Cin * TW * TW * 4, st, x, w, bias, y, B, Cin, F, H, W, Cout, K, y_bf16);
     return hipGetLastError();
 }
 
@@ -155,13 +158,13 @@ hipError_t launch_init_conv(const float* x, const float* w, const float* bias, f
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
-                                                         long npix, int D, int Cout, int lpp) {
+                                                         long npix, int D, int Cout, int lpp, int x_bf16) {
     const int sub = threadIdx.x % lpp, pl = threadIdx.x / lpp, ppb = 256 / lpp;
     for (long pix = (long)blockIdx.x * ppb + pl; pix < npix; pix += (long)gridDim.x * ppb) {
         for (int co = 0; co < Cout; ++co) {
             float s = 0.f;
             for (int c = sub * 4; c < D; c += lpp * 4) {
-                const float4 v = *reinterpret_cast<const float4*>(x + (size_t)pix * D + c);
+                const float4 v = load4_f32_or_bf16(x, (size_t)pix * D + c, x_bf16);
                 s += v.x * w[(size_t)c * Cout + co] + v.y * w[(size_t)(c + 1) * Cout + co]
                    + v.z * w[(size_t)(c + 2) * Cout + co] + v.w * w[(size_t)(c + 3) * Cout + co];
             }
@@ -171,12 +174,12 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
     }
 }
 
-hipError_t launch_final_conv(const float* x, const float* w, const float* bias, float* y, long npix, int D, int Cout, hipStream_t st) {
+hipError_t launch_final_conv(const float* x, const float* w, const float* bias, float* y, long npix, int D, int Cout, int x_bf16, hipStream_t st) {
     int lpp = 1;
     while (lpp * 4 < D && lpp < 16) lpp <<= 1;
     const int ppb = 256 / lpp;
     const int blocks = (int)std::min<long>((npix + ppb - 1) / ppb, 4096);
-    hipLaunchKernelGGL(final_conv_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, Cout, lpp);
+    hipLaunchKernelGGL(final_conv_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, Cout, lpp, x_bf16);
     return hipGetLastError();
 }
 

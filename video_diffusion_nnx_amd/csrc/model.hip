@@ -329,6 +329,7 @@ hipError_t model_pack(const Model* m, const float* p, void* packed, hipStream_t 
 
 struct Fwd {
     const Model* m; const float* p; const char* pk; int B; hipStream_t st;
+    int a16;                                                  // every inter-kernel activation tensor is stored as bf16 (Model::act16)
     float* act; float* temb; float* ss; float* ss_lin; double* stats; char* sla_ws;
     float* slot(int s) const { return act + (size_t)m->slots[s].offset_per_sample * B; }
     double* stat(int i) const { return stats + (size_t)i * B * GN_SLOTS * m->cfg.resnet_groups * 2; }
@@ -346,7 +347,7 @@ static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, 
     a.kind = 0; a.kh = a.kw = 3; a.stride = 1; a.pad = 1;
     a.out_stats = f.stat(r.st1); a.out_groups = G;
     const int half = (m->mode == MODE_BF16);                  // bf16 mode stores the two intra-block tensors y1, y2 as bf16
-    a.y_bf16 = half;
+    a.y_bf16 = half; a.x0_bf16 = f.a16; a.x1_bf16 = f.a16;
     hipError_t e = launch_conv(m->mode, a, f.st);
     if (e != hipSuccess) return e;
     ConvArgs b;
@@ -367,13 +368,14 @@ static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, 
         c.x0 = x0; c.x1 = x1; c.C0 = c0; c.C1 = c1;
         c.wp = f.pk + r.pk_rc; c.bias = f.p + r.rc_b; c.y = f.slot(r.s_rc); c.Cout = r.cout;
         c.NF = a.NF; c.F = a.F; c.H = S; c.W = S; c.kind = 0; c.kh = c.kw = 1; c.stride = 1; c.pad = 0;
+        c.x0_bf16 = f.a16; c.x1_bf16 = f.a16; c.y_bf16 = f.a16;
         e = launch_conv(m->mode, c, f.st);
         if (e != hipSuccess) return e;
         rsrc = f.slot(r.s_rc);
     }
     TailArgs t;
     memset(&t, 0, sizeof(t));
-    t.y2 = f.slot(r.s_y2); t.y2_bf16 = half; t.r = rsrc; t.out = f.slot(r.s_out);
+    t.y2 = f.slot(r.s_y2); t.y2_bf16 = half; t.r = rsrc; t.out = f.slot(r.s_out); t.r_bf16 = f.a16; t.out_bf16 = f.a16;
     t.stats = f.stat(r.st2); t.gn_gamma = f.p + r.b2_gs; t.gn_beta = f.p + r.b2_gb; t.groups = G;
     t.ln_gamma = f.p + r.n2_s; t.ln_beta = f.p + r.n2_b;
     t.C = r.cout; t.batch = f.B; t.pix_per_sample = (long)m->cfg.num_frames * S * S;
@@ -390,6 +392,7 @@ static hipError_t run_attn(const Fwd& f, const AttnP& ap, const float* x, float*
     a.scale = 1.0f / sqrtf((float)m->cfg.attn_dim_head);
     if (temporal) { a.L = (int)Fr; a.nseq = f.B * hw; a.inner = hw; a.inner_stride = ap.C; a.outer_stride = Fr * hw * ap.C; a.tok_stride = hw * ap.C; }
     else { a.L = (int)hw; a.nseq = f.B * Fr; a.inner = 1; a.inner_stride = 0; a.outer_stride = hw * ap.C; a.tok_stride = ap.C; }
+    a.io_bf16 = f.a16;
     return launch_attention(m->mode, a, f.st);
 }
 
@@ -400,6 +403,7 @@ static hipError_t run_sla(const Fwd& f, const SlaP& sp, const float* x, float* y
     memset(&a, 0, sizeof(a));
     a.x = x; a.y = y; a.wq = f.pk + sp.pk[0]; a.wk = f.pk + sp.pk[1]; a.wv = f.pk + sp.pk[2]; a.wo = f.pk + sp.pk_o;
     a.workspace = f.sla_ws; a.C = sp.C; a.heads = m->cfg.attn_heads; a.NF = f.B * m->cfg.num_frames; a.N = S * S;
+    a.io_bf16 = f.a16;
     return launch_sla(m->mode, a, f.st);
 }
 
@@ -412,6 +416,7 @@ static hipError_t run_resample(const Fwd& f, const Level& L, const float* x, flo
     a.NF = f.B * m->cfg.num_frames; a.F = m->cfg.num_frames; a.H = S; a.W = S;
     if (up) { a.kind = 1; a.kh = a.kw = 4; a.stride = 1; a.pad = 0; }
     else { a.kind = 0; a.kh = a.kw = 4; a.stride = 2; a.pad = 1; }
+    a.x0_bf16 = f.a16; a.y_bf16 = f.a16;
     return launch_conv(m->mode, a, f.st);
 }
 
@@ -424,6 +429,7 @@ int model_forward(const Model* m, const float* params, const void* packed, const
     const vdx_config& c = m->cfg;
     Fwd f;
     f.m = m; f.p = params; f.pk = reinterpret_cast<const char*>(packed); f.B = B; f.st = st;
+    f.a16 = (m->act16 && m->mode == MODE_BF16) ? 1 : 0;
     char* w = reinterpret_cast<char*>(workspace);
     f.act = reinterpret_cast<float*>(w); w += ((size_t)m->act_floats_per_sample * B * 4 + 255) / 256 * 256;
     f.temb = reinterpret_cast<float*>(w); w += ((size_t)m->temb_dim * B * 4 + 255) / 256 * 256;
@@ -448,7 +454,7 @@ int model_forward(const Model* m, const float* params, const void* packed, const
         VDX_E(launch_resblock_ss(params, f.temb, m->d_ss_layers, (int)m->ss_layers.size(), f.ss, f.ss_lin, m->temb_dim, B, st));
     }
     // init conv + init temporal attention   (unet3d.py:280-286)
-    VDX_E(launch_init_conv(x, params + m->init_w, params + m->init_b, f.slot(m->s_init), B, c.channels, Fr, S0, S0, m->init_dim, c.init_kernel_size, st));
+    VDX_E(launch_init_conv(x, params + m->init_w, params + m->init_b, f.slot(m->s_init), B, c.channels, Fr, S0, S0, m->init_dim, c.init_kernel_size, f.a16, st));
     VDX_E(run_attn(f, m->init_attn, f.slot(m->s_init), f.slot(m->s_init_attn), 0, true));
     const float* cur = f.slot(m->s_init_attn);
     int cur_c = m->init_dim;
@@ -480,7 +486,7 @@ int model_forward(const Model* m, const float* params, const void* packed, const
         if (L.has_resample) { VDX_E(run_resample(f, L, cur, f.slot(L.s_rs), L.lvl, true)); cur = f.slot(L.s_rs); }
     }
     VDX_E(run_res(f, m->fin, cur, cur_c, f.slot(m->s_init_attn), m->init_dim, 0));                // unet3d.py:377-382
-    VDX_E(launch_final_conv(f.slot(m->fin.s_out), params + m->fin_w, params + m->fin_b, out, (long)B * Fr * S0 * S0, c.dim, m->out_dim, st));
+    VDX_E(launch_final_conv(f.slot(m->fin.s_out), params + m->fin_w, params + m->fin_b, out, (long)B * Fr * S0 * S0, c.dim, m->out_dim, f.a16, st));
 #undef VDX_E
     return VDX_OK;
 }

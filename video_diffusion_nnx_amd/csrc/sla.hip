@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void sla_ctx_kernel(const SlaArgs P) {
     if (cidx >= P.NF * P.nchunk) return;               // uniform across the workgroup
     const int n = cidx / P.nchunk, chunk = cidx % P.nchunk;
     const int R = P.nsub * 64;
-    const float* xf = P.x + (size_t)n * P.N * P.C;
+    const size_t xbase = (size_t)n * P.N * P.C;         // element offset of frame n in x
     const int nkt = P.CPad / KT;
     const char* wk = reinterpret_cast<const char*>(P.wk);
     const char* wv = reinterpret_cast<const char*>(P.wv);
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void sla_ctx_kernel(const SlaArgs P) {
             const int row = i / APIECES, pc = i % APIECES;
             const int c = kt * KT + pc * 4;
             xpre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + row < P.N && c < P.C) xpre[u] = *reinterpret_cast<const float4*>(xf + (size_t)(r0 + row) * P.C + c);
+            if (r0 + row < P.N && c < P.C) xpre[u] = load4_f32_or_bf16(P.x, xbase + (size_t)(r0 + row) * P.C + c, P.io_bf16);
         }
     };
     auto xput = [&]() {
@@ -244,8 +244,7 @@ __global__ __launch_bounds__(256) void sla_out_kernel(const SlaArgs P) {
     const int lp = lane & 15, q = lane >> 4;
     const int tiles = (P.N + 63) / 64;
     const int n = blockIdx.x / tiles, r0 = (blockIdx.x % tiles) * 64;
-    const float* xf = P.x + (size_t)n * P.N * P.C;
-    float* yf = P.y + (size_t)n * P.N * P.C;
+    const size_t xbase = (size_t)n * P.N * P.C;         // element offset of frame n in x and y
     const int nkt = P.CPad / KT;
     const char* wq = reinterpret_cast<const char*>(P.wq);
     const char* wo = reinterpret_cast<const char*>(P.wo);
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(256) void sla_out_kernel(const SlaArgs P) {
             const int row = i / APIECES, pc = i % APIECES;
             const int c = kt * KT + pc * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + row < P.N && c < P.C) v = *reinterpret_cast<const float4*>(xf + (size_t)(r0 + row) * P.C + c);
+            if (r0 + row < P.N && c < P.C) v = load4_f32_or_bf16(P.x, xbase + (size_t)(r0 + row) * P.C + c, P.io_bf16);
             M::store4(xs + row * RS, pc * 4, v);
         }
         for (int i = tid; i < 256 * 8; i += 256) {
@@ -358,11 +357,11 @@ __global__ __launch_bounds__(256) void sla_out_kernel(const SlaArgs P) {
         for (int tn = 0; tn < 4; ++tn) {
             const int row = r0 + tn * 16 + lp;
             if (row >= P.N) continue;
-            const float4 xr = *reinterpret_cast<const float4*>(xf + (size_t)row * P.C + co);
+            const float4 xr = load4_f32_or_bf16(P.x, xbase + (size_t)row * P.C + co, P.io_bf16);
             float4 v;
             v.x = oacc[tmo][tn][0] + xr.x; v.y = oacc[tmo][tn][1] + xr.y;
             v.z = oacc[tmo][tn][2] + xr.z; v.w = oacc[tmo][tn][3] + xr.w;
-            *reinterpret_cast<float4*>(yf + (size_t)row * P.C + co) = v;
+            store4_f32_or_bf16(P.y, xbase + (size_t)row * P.C + co, v, P.io_bf16);
         }
     }
 }
@@ -381,14 +380,14 @@ struct SlaTile {
     static constexpr int PLANE = 64 * ROW_STRIDE;             // one K tile of a sub-tile: [64 pixels][ROW_STRIDE]
     static constexpr int BUF = NKT * PLANE;
     float4 xpre[XP];
-    __device__ __forceinline__ void fetch(const float* xf, int r0, int N, int C, int tid) {
+    __device__ __forceinline__ void fetch(const float* x, size_t xbase, int io_bf16, int r0, int N, int C, int tid) {
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             const int i = tid + 512 * u;
             const int kt = i / (64 * APIECES), rem = i % (64 * APIECES);
             const int row = rem / APIECES, c = kt * M::KT + (rem % APIECES) * 4;
             xpre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + row < N && c < C) xpre[u] = *reinterpret_cast<const float4*>(xf + (size_t)(r0 + row) * C + c);
+            if (r0 + row < N && c < C) xpre[u] = load4_f32_or_bf16(x, xbase + (size_t)(r0 + row) * C + c, io_bf16);
         }
     }
     __device__ __forceinline__ void put(char* xs, int tid) const {
@@ -450,7 +449,7 @@ __global__ __launch_bounds__(512) void sla_ctx8_kernel(const SlaArgs P) {
     const int lp = lane & 15, q = lane >> 4;
     const int n = blockIdx.x / P.nchunk, chunk = blockIdx.x % P.nchunk;
     const int R = P.nsub * 64;
-    const float* xf = P.x + (size_t)n * P.N * P.C;
+    const size_t xbase = (size_t)n * P.N * P.C;         // element offset of frame n in x
 
     // this head's K (tm 0,1) and V (tm 2,3) projection rows as B-operand fragments, resident for the whole chunk
     uint4 wf[NKT][2][4];
@@ -469,7 +468,7 @@ __global__ __launch_bounds__(512) void sla_ctx8_kernel(const SlaArgs P) {
     for (int i = 0; i < 2; ++i) { cacc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; cacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     T t;
-    t.fetch(xf, chunk * R, P.N, P.C, tid);
+    t.fetch(P.x, xbase, P.io_bf16, chunk * R, P.N, P.C, tid);
     t.put(smem, tid);
     __syncthreads();
     for (int sub = 0; sub < P.nsub; ++sub) {
@@ -477,7 +476,7 @@ __global__ __launch_bounds__(512) void sla_ctx8_kernel(const SlaArgs P) {
         if (r0 >= P.N) break;                          // uniform across the workgroup
         const char* xs = smem + (sub & 1) * T::BUF;
         const bool more = (sub + 1 < P.nsub) && (r0 + 64 < P.N);
-        if (more) t.fetch(xf, r0 + 64, P.N, P.C, tid);
+        if (more) t.fetch(P.x, xbase, P.io_bf16, r0 + 64, P.N, P.C, tid);
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {               // two 32-pixel online-softmax steps per sub-tile
             f32x4 acc[2][4];                           // [pixel tile][k0 k1 v0 v1]: lane (lp, q) = (channel lp, pixels 4q+r)
@@ -542,8 +541,7 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
     const int lp = lane & 15, q = lane >> 4;
     const int n = blockIdx.x / P.nchunk, chunk = blockIdx.x % P.nchunk;
     const int R = P.nsub * 64;
-    const float* xf = P.x + (size_t)n * P.N * P.C;
-    float* yf = P.y + (size_t)n * P.N * P.C;
+    const size_t xbase = (size_t)n * P.N * P.C;         // element offset of frame n in x and y
 
     uint4 wqf[NKT][2][2];                              // Wq rows d = tm*16+lp of this head (A operand)
 #pragma unroll
@@ -576,7 +574,7 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
     }
 
     T t;
-    t.fetch(xf, chunk * R, P.N, P.C, tid);
+    t.fetch(P.x, xbase, P.io_bf16, chunk * R, P.N, P.C, tid);
     t.put(smem, tid);
     __syncthreads();
     for (int sub = 0; sub < P.nsub; ++sub) {
@@ -584,7 +582,7 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
         if (r0 >= P.N) break;
         const char* xs = smem + (sub & 1) * T::BUF;
         const bool more = (sub + 1 < P.nsub) && (r0 + 64 < P.N);
-        if (more) t.fetch(xf, r0 + 64, P.N, P.C, tid);
+        if (more) t.fetch(P.x, xbase, P.io_bf16, r0 + 64, P.N, P.C, tid);
         // q[d, n] of this head: lane (lp, q) = (pixel lp, channels 4q+r)
         f32x4 acc[2][4];
 #pragma unroll
@@ -660,9 +658,9 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
             for (int tn = 0; tn < TNO; ++tn) {
                 const int row = r0 + (tn0 + tn) * 16 + lp;
                 if (row >= P.N) continue;
-                const float4 xr = *reinterpret_cast<const float4*>(xf + (size_t)row * P.C + co);
-                *reinterpret_cast<float4*>(yf + (size_t)row * P.C + co) =
-                    make_float4(oacc[tmo][tn][0] + xr.x, oacc[tmo][tn][1] + xr.y, oacc[tmo][tn][2] + xr.z, oacc[tmo][tn][3] + xr.w);
+                const float4 xr = load4_f32_or_bf16(P.x, xbase + (size_t)row * P.C + co, P.io_bf16);
+                store4_f32_or_bf16(P.y, xbase + (size_t)row * P.C + co,
+                                   make_float4(oacc[tmo][tn][0] + xr.x, oacc[tmo][tn][1] + xr.y, oacc[tmo][tn][2] + xr.z, oacc[tmo][tn][3] + xr.w), P.io_bf16);
             }
         }
         if (more) t.put(smem + ((sub + 1) & 1) * T::BUF, tid);

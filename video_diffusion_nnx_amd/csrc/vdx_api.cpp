@@ -93,13 +93,13 @@ int vdx_init_conv(const float* x, const float* kernel, const float* bias, float*
                   int h, int w, int cout, int k, void* stream) {
     if (!x || !kernel || !bias || !y) VDX_FAIL(VDX_ERR_INVALID, "init_conv: null tensor");
     if (k < 1 || k > 15 || !(k & 1) || cin < 1 || cin > 8) VDX_FAIL(VDX_ERR_INVALID, "init_conv: bad kernel size / channels");
-    VDX_HIP(vdx::launch_init_conv(x, kernel, bias, y, batch, cin, frames, h, w, cout, k, (hipStream_t)stream));
+    VDX_HIP(vdx::launch_init_conv(x, kernel, bias, y, batch, cin, frames, h, w, cout, k, 0, (hipStream_t)stream));
     return VDX_OK;
 }
 
 int vdx_final_conv(const float* x, const float* kernel, const float* bias, float* y, long npix, int d, int cout, void* stream) {
     if (!x || !kernel || !bias || !y || d % 4) VDX_FAIL(VDX_ERR_INVALID, "final_conv: bad argument");
-    VDX_HIP(vdx::launch_final_conv(x, kernel, bias, y, npix, d, cout, (hipStream_t)stream));
+    VDX_HIP(vdx::launch_final_conv(x, kernel, bias, y, npix, d, cout, 0, (hipStream_t)stream));
     return VDX_OK;
 }
 
@@ -181,6 +181,19 @@ void vdx_destroy(vdx_handle* h) {
     if (h->model.d_ss_layers) (void)hipFree(h->model.d_ss_layers);
     delete h;
 }
+
+int vdx_set_activation_storage(vdx_handle* h, int bf16) {
+    if (!h) VDX_FAIL(VDX_ERR_INVALID, "set_activation_storage: null handle");
+    if (bf16 && h->model.mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bf16 activation storage needs a VDX_MODE_BF16 handle");
+    const int v = bf16 ? 1 : 0;
+    if (v != h->model.act16) {                       // a cached sampling graph was captured with the other storage
+        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+        if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+        h->model.act16 = v;
+    }
+    return VDX_OK;
+}
+int vdx_get_activation_storage(const vdx_handle* h) { return h ? h->model.act16 : 0; }
 
 int vdx_param_count(const vdx_handle* h) { return h ? (int)h->model.params.size() : 0; }
 long vdx_param_total(const vdx_handle* h) { return h ? h->model.param_total : 0; }
@@ -302,7 +315,7 @@ int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, fl
     vdx_handle::GraphKey key;
     memset(&key, 0, sizeof(key));
     key.p[0] = params; key.p[1] = packed; key.p[2] = img; key.p[3] = eps_buf; key.p[4] = t_dev; key.p[5] = step_dev;
-    key.p[6] = tables; key.p[7] = cond; key.seed = seed; key.i[0] = timesteps; key.i[1] = clip_denoised; key.i[2] = batch;
+    key.p[6] = tables; key.p[7] = cond; key.seed = seed; key.i[0] = timesteps; key.i[1] = clip_denoised | (h->model.act16 << 8); key.i[2] = batch;
     key.i[3] = (int)(uintptr_t)workspace; key.ws = workspace_bytes ^ (size_t)(uintptr_t)stream;
     int done = 0;
     if (!h->graph_exec || memcmp(&key, &h->graph_key, sizeof(key)) != 0) {
@@ -412,6 +425,7 @@ int vdx_unet_backward(vdx_handle* h, const float* params, const void* packed, co
                       void* bwd_workspace, size_t bwd_workspace_bytes, float* grads, int stage_hi, int stage_lo, int batch, void* stream) {
     if (!h || !params || !packed || !packed_t || !x || !time || !d_out || !fwd_workspace || !bwd_workspace || !grads) VDX_FAIL(VDX_ERR_INVALID, "unet_backward: null argument");
     if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "unet_backward: handle was created without a GPU");
+    if (h->model.act16) VDX_FAIL(VDX_ERR_STATE, "unet_backward: the forward ran with bf16 activation storage; the backward reads fp32 slots");
     return vdx::model_backward(&h->model, &h->bwd, params, packed, packed_t, x, time, cond, cond_mask, null_all, d_out, fwd_workspace,
                                bwd_workspace, bwd_workspace_bytes, grads, stage_hi, stage_lo, batch, (hipStream_t)stream);
 }

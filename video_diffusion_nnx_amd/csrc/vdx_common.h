@@ -111,6 +111,12 @@ __device__ __forceinline__ float4 load4_f32_or_bf16(const float* base, size_t i,
     return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u));
 }
 
+// store 4 consecutive channels to a tensor stored as fp32 or bf16 (element index i, a multiple of 4)
+__device__ __forceinline__ void store4_f32_or_bf16(float* base, size_t i, float4 v, int is_bf16) {
+    if (!is_bf16) *reinterpret_cast<float4*>(base + i) = v;
+    else *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + i * 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+
 // sum over the 16 lanes that share (lane >> 4)
 __device__ __forceinline__ float reduce16(float v) {
     v += __shfl_xor(v, 1);

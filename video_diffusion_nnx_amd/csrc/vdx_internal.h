@@ -28,6 +28,7 @@ struct ConvArgs {
     // epilogue: GroupNorm partial statistics of the output (or null)
     double* out_stats; int out_groups;
     int x0_bf16, y_bf16;            // x0 / y are stored as bf16 (the intra-ResnetBlock tensors in bf16 mode); y_bf16 excludes res
+    int x1_bf16;                    // x1 stored as bf16 (bf16 activation storage)
     const float* res;               // optional residual added to the output: y = conv + bias + res  ([.., Cout] like y)
     int wrows, wrow0;               // packed weight rows per tap / first row (0,0 = Cout rows from 0): slices a wider packing
     // completed by launch_conv
@@ -39,6 +40,7 @@ struct ConvArgs {
 struct TailArgs {
     const float* y2; const float* r; float* out;
     int y2_bf16;                    // y2 stored as bf16
+    int r_bf16, out_bf16;           // r / out stored as bf16 (bf16 activation storage)
     const double* stats; const float* gn_gamma; const float* gn_beta; int groups;
     const float* ln_gamma; const float* ln_beta;
     int C; int batch; long pix_per_sample;
@@ -58,8 +60,8 @@ struct SsLayer { long w_off, b_off, g_off, be_off, out_off; int n; int pad_; };
 
 hipError_t launch_resblock_tail(TailArgs a, hipStream_t st);
 hipError_t launch_init_conv(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int F, int H, int W,
-                            int Cout, int K, hipStream_t st);
-hipError_t launch_final_conv(const float* x, const float* w, const float* bias, float* y, long npix, int D, int Cout, hipStream_t st);
+                            int Cout, int K, int y_bf16, hipStream_t st);
+hipError_t launch_final_conv(const float* x, const float* w, const float* bias, float* y, long npix, int D, int Cout, int x_bf16, hipStream_t st);
 hipError_t launch_time_mlp(const TimeMlpArgs& a, int B, hipStream_t st);
 hipError_t launch_resblock_ss(const float* params, const float* temb, const SsLayer* layers, int nlayers, float* ss_base,
                               float* lin_base, int temb_dim, int B, hipStream_t st);
@@ -72,6 +74,7 @@ struct AttnArgs {
     int C, heads, L;
     long nseq, inner, inner_stride, outer_stride, tok_stride;
     float scale;
+    int io_bf16;                              // x and y stored as bf16 (bf16 activation storage); strides stay in elements
     int CPad, HDPad;                          // completed by the launcher
     int dbg;                                  // timing-only ablation bits (env VDX_ATTN_DBG); 0 in normal use
 };
@@ -84,6 +87,7 @@ struct SlaArgs {
     const void* wo;                                    // packed [C][256]
     void* workspace;                                   // sla_workspace_bytes()
     int C, heads, NF, N;
+    int io_bf16;                                       // x and y stored as bf16 (bf16 activation storage)
     // completed by the launcher
     int CPad, nsub, nchunk; float* part; void* ctxT;
 };

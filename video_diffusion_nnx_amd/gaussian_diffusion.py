@@ -87,7 +87,10 @@ def is_list_str(x) -> bool:
 class GaussianDiffusion:
     def __init__(self, denoise_fn: Unet3D, *, image_size: int, num_frames: int, text_use_bert_cls: bool = False,
                  channels: int = 3, timesteps: int = 1000, loss_type: str = 'l1', use_dynamic_thres: bool = False,
-                 dynamic_thres_percentile: float = 0.9):
+                 dynamic_thres_percentile: float = 0.9, sample_act_bf16: bool = True):
+        # sample_act_bf16 (extension): with a mode='bf16' Unet3D the sampling loops store the UNet's inter-kernel activations
+        # as bf16 (vdx_set_activation_storage); training forwards are unaffected
+        self.sample_act_bf16 = sample_act_bf16
         self.channels = channels
         self.image_size = image_size
         self.num_frames = num_frames
@@ -184,6 +187,16 @@ class GaussianDiffusion:
         cur = torch.cuda.current_stream(self.device)
         st = self._sample_stream
         st.wait_stream(cur)
+        keep_storage = unet.act_bf16
+        unet.act_bf16 = bool(self.sample_act_bf16 and unet.mode == 'bf16')
+        try:
+            out = self._p_sample_loop_on(st, unet, shape, B, T, seed, cond, cond_scale, use_graph, x_T)
+        finally:
+            unet.act_bf16 = keep_storage
+        cur.wait_stream(st)
+        return out
+
+    def _p_sample_loop_on(self, st, unet, shape, B, T, seed, cond, cond_scale, use_graph, x_T):
         with torch.cuda.stream(st):
             img = self.randn(shape, seed, 0) if x_T is None else self._dev(x_T).clone()
             guided = cond is not None and unet.has_cond and cond_scale != 1
@@ -197,6 +210,7 @@ class GaussianDiffusion:
             else:
                 condd = None if (cond is None or not unet.has_cond) else self._dev(cond)
                 h = unet.handle(self.num_frames, self.image_size)
+                unet.apply_activation_storage(h)
                 ws = unet.workspace(B, self.num_frames, self.image_size)
                 eps = torch.empty(B, self.num_frames, self.image_size, self.image_size, unet.out_dim, dtype=torch.float32, device=self.device)
                 t_dev = torch.full((B,), T - 1, dtype=torch.int32, device=self.device)
@@ -206,7 +220,6 @@ class GaussianDiffusion:
                                           int(use_graph), L.stream_ptr()))
             out = torch.empty_like(img)
             L.check(vdx_affine(L.ptr(img), L.ptr(out), img.numel(), 0.5, 0.5, L.stream_ptr()))     # unnormalize_img
-        cur.wait_stream(st)
         return out
 
     def sample(self, key, cond=None, cond_scale: float = 1.0, batch_size: int = 16, **kw):

@@ -57,6 +57,8 @@ vdx_workspace_bytes = L._sig('vdx_workspace_bytes', C.c_size_t, [_vp, C.c_int])
 vdx_slot_count = L._sig('vdx_slot_count', C.c_int, [_vp])
 vdx_slot_info = L._sig('vdx_slot_info', C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)])
 vdx_num_stages = L._sig('vdx_num_stages', C.c_int, [_vp])
+vdx_set_activation_storage = L._sig('vdx_set_activation_storage', C.c_int, [_vp, C.c_int])
+vdx_get_activation_storage = L._sig('vdx_get_activation_storage', C.c_int, [_vp])
 vdx_packed_bwd_bytes = L._sig('vdx_packed_bwd_bytes', C.c_size_t, [_vp])
 vdx_pack_params_bwd = L._sig('vdx_pack_params_bwd', C.c_int, [_vp, _vp, _vp, _vp])
 vdx_bwd_workspace_bytes = L._sig('vdx_bwd_workspace_bytes', C.c_size_t, [_vp, C.c_int])
@@ -131,6 +133,9 @@ class Unet3D:
         self.resnet_groups = resnet_groups
         self.mode = mode
         self.mode_id = L.MODES[mode]
+        # bf16 mode only: store every inter-kernel activation as bf16 (inference).  GaussianDiffusion turns it on for its
+        # sampling loops; forwards that feed backward() need it off (the backward reads the fp32 slots).
+        self.act_bf16 = False
         self.device = torch.device(device) if device is not None else torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')
         self._handles: Dict[Tuple[int, int], _Handle] = {}
         self._ws: Dict[Tuple[int, int, int], torch.Tensor] = {}
@@ -287,6 +292,11 @@ class Unet3D:
                                   L.ptr(cond) if self.has_cond else 0, L.ptr(cm), null_all, L.ptr(d_out), L.ptr(ws), L.ptr(bws), bws.numel(),
                                   L.ptr(grads), stage_hi, stage_lo, B, L.stream_ptr()))
 
+    def apply_activation_storage(self, h) -> None:
+        if self.act_bf16 and self.mode != 'bf16':
+            raise ValueError("act_bf16 needs mode='bf16'")
+        L.check(vdx_set_activation_storage(h.ptr, int(bool(self.act_bf16))))
+
     def workspace(self, batch: int, frames: int, size: int) -> torch.Tensor:
         key = (batch, frames, size)
         if key not in self._ws:
@@ -296,6 +306,8 @@ class Unet3D:
 
     def slot(self, name: str, batch: int, frames: int, size: int) -> torch.Tensor:
         """Flat view of a named intermediate of the LAST forward at this geometry (parity/debug tool)."""
+        if vdx_get_activation_storage(self.handle(frames, size).ptr):
+            raise RuntimeError('slot(): the last forward stored bf16 activations; run with act_bf16 = False to inspect slots')
         n, off = self.handle(frames, size).slot_table()[name]
         ws = self.workspace(batch, frames, size).view(torch.float32)
         return ws[off * batch: off * batch + n * batch]
@@ -329,6 +341,7 @@ class Unet3D:
             else:   # prob_mask_like (utils.py:85-101) with the host generator (Q14)
                 cm = (torch.rand(B, device=self.device) < null_cond_prob).to(torch.uint8)
         h = self.handle(Fr, H)
+        self.apply_activation_storage(h)
         ws = self.workspace(B, Fr, H)
         if out is None:
             out = torch.empty(B, Fr, H, W, self.out_dim, dtype=torch.float32, device=self.device)
