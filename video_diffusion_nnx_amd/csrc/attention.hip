@@ -408,11 +408,15 @@ __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
 // values, 1/sqrt(d) is folded into the exponent, the key mask exists only for L < 16, cross-row reductions are permlane
 // swaps, and every address is (uniform base of the sub-tile) + (per-thread constant).  Host guarantees inner % 4 == 0 and
 // nseq % 4 == 0 (the 4 sequences of a sub-tile share their outer index) and 32-bit per-thread offsets.
-template <int MODE, int NKT, int TMO, int TNO>
+// IO16: x and y are bf16 tensors (bf16 activation storage): pieces are 8 channels = 16 bytes, copied into the bf16 LDS tile
+// as they are, and the raw piece is the residual.
+template <int MODE, int NKT, int TMO, int TNO, bool IO16>
 __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, const int nsub) {
     using M = Mma<MODE>;
+    static_assert(!IO16 || MODE == MODE_BF16, "bf16 activation storage implies bf16 MFMA operands");
     constexpr int KT = M::KT, KC = M::KC, RS = ROW_STRIDE, D = 32, HD = 256;
-    constexpr int APIECES = KT / 4;
+    constexpr int PCH = IO16 ? 8 : 4;                                 // channels per 16-byte piece
+    constexpr int APIECES = KT / PCH;
     constexpr int XP = 64 * APIECES * NKT / 512;
     constexpr int PLANE = 64 * RS, BUF = NKT * PLANE;
     constexpr int RSO = HD * M::ES + 16;
@@ -435,9 +439,9 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
         const int i = tid + 512 * u;
         const int kt = i / (64 * APIECES), rem = i % (64 * APIECES);
         const int ridx = rem / APIECES, pc = rem % APIECES;          // ridx = token * 4 + sequence: 4 adjacent sequences =
-        const int sl = ridx & 3, tok = ridx >> 2, c = kt * KT + pc * 4;   // one contiguous run per token
+        const int sl = ridx & 3, tok = ridx >> 2, c = kt * KT + pc * PCH; // one contiguous run per token
         goff[u] = (unsigned)(sl * P.inner_stride + tok * P.tok_stride + c);
-        xoff[u] = kt * PLANE + (sl * 16 + tok) * RS + pc * 4 * M::ES;   // LDS row = sequence * 16 + token
+        xoff[u] = kt * PLANE + (sl * 16 + tok) * RS + pc * PCH * M::ES; // LDS row = sequence * 16 + token
         yoff[u] = (sl * 16 + tok) * RSY + c * 4;
         pvalid[u] = tok < P.L && c < P.C;
     }
@@ -445,19 +449,22 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
         const unsigned inner = (unsigned)P.inner;
         return (long)((unsigned)sg0 / inner) * P.outer_stride + (long)((unsigned)sg0 % inner) * P.inner_stride;
     };
-    float4 xpre[XP];
+    float4 xpre[XP];                                   // IO16: the 16 raw bytes (8 bf16) travel in a float4
     auto fetch = [&](long sg0) {
         const size_t xb = (size_t)tile_base(sg0);
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             xpre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pvalid[u]) xpre[u] = load4_f32_or_bf16(P.x, xb + goff[u], P.io_bf16);
+            if (pvalid[u]) {
+                if (IO16) xpre[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(P.x) + (xb + goff[u]) * 2);
+                else xpre[u] = load4_f32_or_bf16(P.x, xb + goff[u], P.io_bf16);
+            }
         }
     };
     auto put = [&](char* xs) {
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
-            if (MODE == MODE_F32) *reinterpret_cast<float4*>(xs + xoff[u]) = xpre[u];
+            if (IO16 || MODE == MODE_F32) *reinterpret_cast<float4*>(xs + xoff[u]) = xpre[u];
             else *reinterpret_cast<uint2*>(xs + xoff[u]) = make_uint2(pack_bf16x2(xpre[u].x, xpre[u].y), pack_bf16x2(xpre[u].z, xpre[u].w));
         }
     };
@@ -586,16 +593,27 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
         for (int u = 0; u < XP; ++u) {
             if (!pvalid[u]) continue;
             const float4 o4 = *reinterpret_cast<const float4*>(ys + yoff[u]);
-            store4_f32_or_bf16(P.y, yb + goff[u], make_float4(o4.x + xcur[u].x, o4.y + xcur[u].y, o4.z + xcur[u].z, o4.w + xcur[u].w), P.io_bf16);
+            if (IO16) {
+                const float4 o5 = *reinterpret_cast<const float4*>(ys + yoff[u] + 16);
+                const unsigned r0 = __float_as_uint(xcur[u].x), r1 = __float_as_uint(xcur[u].y), r2 = __float_as_uint(xcur[u].z), r3 = __float_as_uint(xcur[u].w);
+                uint4 w;
+                w.x = pack_bf16x2(o4.x + __uint_as_float(r0 << 16), o4.y + __uint_as_float(r0 & 0xFFFF0000u));
+                w.y = pack_bf16x2(o4.z + __uint_as_float(r1 << 16), o4.w + __uint_as_float(r1 & 0xFFFF0000u));
+                w.z = pack_bf16x2(o5.x + __uint_as_float(r2 << 16), o5.y + __uint_as_float(r2 & 0xFFFF0000u));
+                w.w = pack_bf16x2(o5.z + __uint_as_float(r3 << 16), o5.w + __uint_as_float(r3 & 0xFFFF0000u));
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(P.y) + (yb + goff[u]) * 2) = w;
+            } else {
+                store4_f32_or_bf16(P.y, yb + goff[u], make_float4(o4.x + xcur[u].x, o4.y + xcur[u].y, o4.z + xcur[u].z, o4.w + xcur[u].w), P.io_bf16);
+            }
         }
     }
 }
 
-template <int MODE, int NKT, int TMO, int TNO>
+template <int MODE, int NKT, int TMO, int TNO, bool IO16>
 static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
     using M = Mma<MODE>;
     const size_t lds = 2 * (size_t)NKT * 64 * ROW_STRIDE + (size_t)64 * (256 * M::ES + 16) + (size_t)64 * (NKT * M::KT * 4 + 16);
-    auto kfn = attention_h8_kernel<MODE, NKT, TMO, TNO>;
+    auto kfn = attention_h8_kernel<MODE, NKT, TMO, TNO, IO16>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -658,9 +676,13 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
                        3 * a.inner_stride + 15 * a.tok_stride + a.C < (1L << 31);
     if (h8_ok && use_reg && use_h8) {
         const int nkt = a.CPad / Mma<MODE>::KT;
-        if (a.C == 64 && nkt == 1) return launch_attn_h8_t<MODE, 1, 1, 2>(a, st);
-        if (a.C == 64 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 2>(a, st);
-        if (a.C == 128 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 4>(a, st);
+        if constexpr (MODE == MODE_BF16) {
+            if (a.io_bf16 && a.C == 64) return launch_attn_h8_t<MODE, 1, 1, 2, true>(a, st);
+            if (a.io_bf16 && a.C == 128) return launch_attn_h8_t<MODE, 2, 1, 4, true>(a, st);
+        }
+        if (a.C == 64 && nkt == 1) return launch_attn_h8_t<MODE, 1, 1, 2, false>(a, st);
+        if (a.C == 64 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 2, false>(a, st);
+        if (a.C == 128 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 4, false>(a, st);
     }
     if (a.L <= 16 && use_reg) return launch_attn_reg<MODE>(a, st);
     if (a.L <= 16) return launch_attn_l<MODE, 16>(a, st);

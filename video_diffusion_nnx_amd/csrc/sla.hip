@@ -372,22 +372,27 @@ __global__ __launch_bounds__(256) void sla_out_kernel(const SlaArgs P) {
 // fragments for the whole chunk, and the projections are oriented so that their accumulators are directly the operands
 // of the following K=16 MFMA (Mma::mma16): no q/k/v transposes through LDS, one barrier per sub-tile.
 
-template <int MODE, int NKT>
+template <int MODE, int NKT, bool IO16>
 struct SlaTile {
     using M = Mma<MODE>;
-    static constexpr int APIECES = M::KT / 4;                 // float4 pieces per pixel per K tile
+    static_assert(!IO16 || MODE == MODE_BF16, "bf16 activation storage implies bf16 MFMA operands");
+    static constexpr int PCH = IO16 ? 8 : 4;                  // channels per 16-byte piece (IO16: x is a bf16 tensor)
+    static constexpr int APIECES = M::KT / PCH;               // pieces per pixel per K tile
     static constexpr int XP = 64 * APIECES * NKT / 512;       // pieces per thread
     static constexpr int PLANE = 64 * ROW_STRIDE;             // one K tile of a sub-tile: [64 pixels][ROW_STRIDE]
     static constexpr int BUF = NKT * PLANE;
-    float4 xpre[XP];
+    float4 xpre[XP];                                          // IO16: 16 raw bytes (8 bf16), copied to the bf16 LDS tile as they are
     __device__ __forceinline__ void fetch(const float* x, size_t xbase, int io_bf16, int r0, int N, int C, int tid) {
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             const int i = tid + 512 * u;
             const int kt = i / (64 * APIECES), rem = i % (64 * APIECES);
-            const int row = rem / APIECES, c = kt * M::KT + (rem % APIECES) * 4;
+            const int row = rem / APIECES, c = kt * M::KT + (rem % APIECES) * PCH;
             xpre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r0 + row < N && c < C) xpre[u] = load4_f32_or_bf16(x, xbase + (size_t)(r0 + row) * C + c, io_bf16);
+            if (r0 + row < N && c < C) {
+                if (IO16) xpre[u] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + (xbase + (size_t)(r0 + row) * C + c) * 2);
+                else xpre[u] = load4_f32_or_bf16(x, xbase + (size_t)(r0 + row) * C + c, io_bf16);
+            }
         }
     }
     __device__ __forceinline__ void put(char* xs, int tid) const {
@@ -395,7 +400,9 @@ struct SlaTile {
         for (int u = 0; u < XP; ++u) {
             const int i = tid + 512 * u;
             const int kt = i / (64 * APIECES), rem = i % (64 * APIECES);
-            M::store4(xs + kt * PLANE + (rem / APIECES) * ROW_STRIDE, (rem % APIECES) * 4, xpre[u]);
+            char* dst = xs + kt * PLANE + (rem / APIECES) * ROW_STRIDE;
+            if (IO16) *reinterpret_cast<float4*>(dst + (rem % APIECES) * 16) = xpre[u];
+            else M::store4(dst, (rem % APIECES) * 4, xpre[u]);
         }
     }
 };
@@ -439,10 +446,10 @@ __device__ __forceinline__ void ctx8_softmax_step(f32x4 (&acc)[2][4], float (&m_
     }
 }
 
-template <int MODE, int NKT>
+template <int MODE, int NKT, bool IO16>
 __global__ __launch_bounds__(512) void sla_ctx8_kernel(const SlaArgs P) {
     using M = Mma<MODE>;
-    using T = SlaTile<MODE, NKT>;
+    using T = SlaTile<MODE, NKT, IO16>;
     constexpr int RS = ROW_STRIDE;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // xs[2][NKT][64][RS]
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
@@ -526,10 +533,10 @@ __global__ __launch_bounds__(512) void sla_ctx8_kernel(const SlaArgs P) {
 
 // q projection + softmax over D + out = ctx^T q per head in registers; the heads meet in LDS (os) for the to_out GEMM,
 // which the 8 waves split by (output-channel tile, pixel tile).  TMO x TNO = tiles per wave: C/16 * 4 / 8.
-template <int MODE, int NKT, int TMO, int TNO>
+template <int MODE, int NKT, int TMO, int TNO, bool IO16>
 __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const SlaArgs P) {
     using M = Mma<MODE>;
-    using T = SlaTile<MODE, NKT>;
+    using T = SlaTile<MODE, NKT, IO16>;
     constexpr int RS = ROW_STRIDE, KC = M::KC, HD = 256;
     constexpr int RSO = HD * M::ES + 16;
     constexpr int NCHO = HD / KC;
@@ -700,14 +707,14 @@ static hipError_t launch_sla_out_t(const SlaArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int MODE, int NKT, int TMO, int TNO>
+template <int MODE, int NKT, int TMO, int TNO, bool IO16>
 static hipError_t launch_sla8_t(const SlaArgs& a, hipStream_t st) {
     using M = Mma<MODE>;
-    using T = SlaTile<MODE, NKT>;
+    using T = SlaTile<MODE, NKT, IO16>;
     const size_t lds_ctx = 2 * (size_t)T::BUF;
     const size_t lds_out = lds_ctx + (size_t)64 * (256 * M::ES + 16);
-    auto kc = sla_ctx8_kernel<MODE, NKT>;
-    auto ko = sla_out8_kernel<MODE, NKT, TMO, TNO>;
+    auto kc = sla_ctx8_kernel<MODE, NKT, IO16>;
+    auto ko = sla_out8_kernel<MODE, NKT, TMO, TNO, IO16>;
     hipError_t e;
     if (lds_ctx > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ctx)) != hipSuccess) return e;
     if (lds_out > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(ko), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_out)) != hipSuccess) return e;
@@ -731,9 +738,13 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
     static const bool generic_only = getenv("VDX_SLA_GENERIC") != nullptr;
     const int nkt = a.CPad / M::KT;
     if (a.heads == 8 && a.C % 64 == 0 && !generic_only) {     // one wave per head; x tile double-buffered in LDS
-        if (nkt == 1 && a.C == 64) return launch_sla8_t<MODE, 1, 1, 2>(a, st);
-        if (nkt == 2 && a.C == 64) return launch_sla8_t<MODE, 2, 1, 2>(a, st);
-        if (nkt == 2 && a.C == 128) return launch_sla8_t<MODE, 2, 1, 4>(a, st);
+        if constexpr (MODE == MODE_BF16) {
+            if (a.io_bf16 && a.C == 64) return launch_sla8_t<MODE, 1, 1, 2, true>(a, st);
+            if (a.io_bf16 && a.C == 128) return launch_sla8_t<MODE, 2, 1, 4, true>(a, st);
+        }
+        if (nkt == 1 && a.C == 64) return launch_sla8_t<MODE, 1, 1, 2, false>(a, st);
+        if (nkt == 2 && a.C == 64) return launch_sla8_t<MODE, 2, 1, 2, false>(a, st);
+        if (nkt == 2 && a.C == 128) return launch_sla8_t<MODE, 2, 1, 4, false>(a, st);
     }
     const size_t lds1 = 1024 + (size_t)128 * ROW_STRIDE + (size_t)64 * RSE;
     hipLaunchKernelGGL(sla_ctx_kernel<MODE>, dim3(((a.NF * a.nchunk + 7) / 8) * 8 * a.heads), dim3(256), lds1, st, a);
