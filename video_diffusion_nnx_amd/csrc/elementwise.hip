@@ -231,8 +231,93 @@ __global__ __launch_bounds__(256) void init_conv_kernel(const float* __restrict_
     }
 }
 
+// bf16-mode stem for Cin == 1 on MFMA: im2col of the 16x16 pixel tile in LDS (row = pixel, K = ky * 8 + kx with the kx = 7
+// slot zero: one 16-byte LDS write per kernel row), weights repacked to [Cout][K] bf16 per workgroup, 64 output channels.
+// Same arithmetic class as every other conv of bf16 mode (bf16 operands, fp32 accumulate).
+__global__ __launch_bounds__(256) void init_conv_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ y,
+                                                             int B, int F, int H, int W, int Cout, int K, int y_bf16) {
+    using M = Mma<MODE_BF16>;
+    constexpr int KP = 64, RSK = KP * 2 + 16;                 // K (padded) and LDS row stride in bytes
+    constexpr int TWM = 16 + 8 - 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* tile = reinterpret_cast<float*>(smem);             // [TW][TW] input halo tile, TW = 16 + K - 1
+    char* wl = smem + ((TWM * TWM * 4 + 15) / 16) * 16;       // [64 co][RSK]
+    char* col = wl + 64 * RSK;                                // [256 px][RSK]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    const int pad = K / 2, TW = 16 + K - 1;
+    const int tx = blockIdx.x % ((W + 15) / 16), ty = blockIdx.x / ((W + 15) / 16);
+    const int f = blockIdx.y % F, b = blockIdx.y / F;
+    for (int i = tid; i < TW * TW; i += 256) {
+        const int gy = ty * 16 + i / TW - pad, gx = tx * 16 + i % TW - pad;
+        tile[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[(((size_t)b * F + f) * H + gy) * W + gx] : 0.f;
+    }
+    for (int i = tid; i < 64 * RSK / 4; i += 256) reinterpret_cast<unsigned*>(wl)[i] = 0u;
+    __syncthreads();
+    for (int i = tid; i < K * K * Cout; i += 256) {           // Flax (kh, kw, 1, Cout)
+        const int co = i % Cout, t = i / Cout;
+        if (co < 64) M::store1(wl + co * RSK, (t / K) * 8 + (t % K), w[i]);
+    }
+    {   // this thread's pixel row of the im2col matrix
+        const int py = tid >> 4, px = tid & 15;
+        char* row = col + tid * RSK;
+#pragma unroll
+        for (int ky = 0; ky < 8; ++ky) {
+            float v[8];
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx) v[kx] = (ky < K && kx < K) ? tile[(py + ky) * TW + px + kx] : 0.f;
+            *reinterpret_cast<uint4*>(row + ky * 16) =
+                make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        }
+    }
+    __syncthreads();
+    f32x4 acc[4][4];                                          // [co tile][pixel tile of this wave]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) {
+        uint4 af[4], bf[4];
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) af[tm] = *reinterpret_cast<const uint4*>(wl + (tm * 16 + lp) * RSK + ch * 64 + q * 16);
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(col + ((wv * 4 + tn) * 16 + lp) * RSK + ch * 64 + q * 16);
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
+    }
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int p = (wv * 4 + tn) * 16 + lp;
+        const int oy = ty * 16 + (p >> 4), ox = tx * 16 + (p & 15);
+        if (oy >= H || ox >= W) continue;
+        const size_t ob = ((((size_t)b * F + f) * H + oy) * W + ox) * Cout;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) {
+            const int co = tm * 16 + 4 * q;
+            if (co >= Cout) continue;
+            const float4 bi = *reinterpret_cast<const float4*>(bias + co);
+            store4_f32_or_bf16(y, ob + co, make_float4(acc[tm][tn][0] + bi.x, acc[tm][tn][1] + bi.y, acc[tm][tn][2] + bi.z, acc[tm][tn][3] + bi.w), y_bf16);
+        }
+    }
+}
+
 hipError_t launch_init_conv(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int F, int H, int W,
                             int Cout, int K, int y_bf16, hipStream_t st) {
+    return launch_init_conv_mode(MODE_F32, x, w, bias, y, B, Cin, F, H, W, Cout, K, y_bf16, st);
+}
+
+hipError_t launch_init_conv_mode(int mode, const float* x, const float* w, const float* bias, float* y, int B, int Cin, int F, int H, int W,
+                                 int Cout, int K, int y_bf16, hipStream_t st) {
+    if (mode == MODE_BF16 && Cin == 1 && K <= 8 && Cout <= 64 && Cout % 4 == 0) {
+        const size_t lds = ((23 * 23 * 4 + 15) / 16) * 16 + (size_t)(64 + 256) * (64 * 2 + 16);
+        dim3 grid(((W + 15) / 16) * ((H + 15) / 16), B * F);
+        hipLaunchKernelGGL(init_conv_mfma_kernel, grid, dim3(256), lds, st, x, w, bias, y, B, F, H, W, Cout, K, y_bf16);
+        return hipGetLastError();
+    }
     const int TW = 16 + K - 1;
     dim3 grid(((W + 15) / 16) * ((H + 15) / 16), B * F, (Cout + 15) / 16);
     hipLaunchKernelGGL(init_conv_kernel, grid, dim3(256), (size_t)Cin * TW * TW * 4, st, x, w, bias, y, B, Cin, F, H, W, Cout, K, y_bf16);

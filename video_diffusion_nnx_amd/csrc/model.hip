@@ -454,7 +454,7 @@ int model_forward(const Model* m, const float* params, const void* packed, const
         VDX_E(launch_resblock_ss(params, f.temb, m->d_ss_layers, (int)m->ss_layers.size(), f.ss, f.ss_lin, m->temb_dim, B, st));
     }
     // init conv + init temporal attention   (unet3d.py:280-286)
-    VDX_E(launch_init_conv(x, params + m->init_w, params + m->init_b, f.slot(m->s_init), B, c.channels, Fr, S0, S0, m->init_dim, c.init_kernel_size, f.a16, st));
+    VDX_E(launch_init_conv_mode(m->mode, x, params + m->init_w, params + m->init_b, f.slot(m->s_init), B, c.channels, Fr, S0, S0, m->init_dim, c.init_kernel_size, f.a16, st));
     VDX_E(run_attn(f, m->init_attn, f.slot(m->s_init), f.slot(m->s_init_attn), 0, true));
     const float* cur = f.slot(m->s_init_attn);
     int cur_c = m->init_dim;

@@ -61,6 +61,8 @@ struct SsLayer { long w_off, b_off, g_off, be_off, out_off; int n; int pad_; };
 hipError_t launch_resblock_tail(TailArgs a, hipStream_t st);
 hipError_t launch_init_conv(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int F, int H, int W,
                             int Cout, int K, int y_bf16, hipStream_t st);
+hipError_t launch_init_conv_mode(int mode, const float* x, const float* w, const float* bias, float* y, int B, int Cin, int F, int H, int W,
+                                 int Cout, int K, int y_bf16, hipStream_t st);     // bf16 mode: MFMA im2col kernel when Cin == 1
 hipError_t launch_final_conv(const float* x, const float* w, const float* bias, float* y, long npix, int D, int Cout, int x_bf16, hipStream_t st);
 hipError_t launch_time_mlp(const TimeMlpArgs& a, int B, hipStream_t st);
 hipError_t launch_resblock_ss(const float* params, const float* temb, const SsLayer* layers, int nlayers, float* ss_base,
