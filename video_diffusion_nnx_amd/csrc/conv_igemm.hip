@@ -80,9 +80,9 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
 
     for (int i = tid; i < 2 * BC; i += NT) chs[i] = 0.f;
     for (int hp = tid; hp < HPX; hp += NT) {
-        const int patch = hp / (IH * IW);
+        const int patch = div_magic(hp, P.m_ihiw);
         const int r = hp - patch * (IH * IW);
-        const int iy = r / IW, ix = r - iy * IW;
+        const int iy = div_magic(r, P.m_iw), ix = r - iy * IW;
         const int gy = iy0 + iy, gx = ix0 + ix, f = f0 + patch;
         hp_pix[hp] = (f < P.NF && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W) ? ((f * P.H + gy) * P.W + gx) : -1;
     }
@@ -122,9 +122,9 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int p = wpx * (TN * 16) + tn * 16 + lp;
-        const int patch = p / (P.PH * P.PW);
+        const int patch = div_magic(p, P.m_phpw);
         const int r = p - patch * (P.PH * P.PW);
-        const int py = r / P.PW, px = r - py * P.PW;
+        const int py = div_magic(r, P.m_pw), px = r - py * P.PW;
         pixoff[tn] = ((patch * IH + py * P.stride) * IW + px * P.stride) * RS + q * 16;
         const int oy = oy0 + py, ox = ox0 + px, f = f0 + patch;
         const bool ok = (f < P.NF) && (oy < P.Ho) && (ox < P.Wo);
@@ -442,6 +442,9 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     a.tiles_x = (a.Wo + a.PW - 1) / a.PW;
     const int IH = (a.PH - 1) * a.stride + K, IW = (a.PW - 1) * a.stride + K;
     const int HPX = a.NP * IH * IW;
+    auto magic = [](int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; };      // every divisor here is >= 2
+    a.m_ihiw = magic(IH * IW); a.m_iw = magic(IW); a.m_phpw = magic(a.PH * a.PW); a.m_pw = magic(a.PW);
+    if (IW < 2 || a.PW < 2) return hipErrorInvalidValue;
     size_t lds = 2 * BC * 4 + ((HPX * 4 + 15) / 16) * 16 + (a.pro ? (2 * a.CinPad * 4 + 64 * 4) : 0)
                + (size_t)HPX * ROW_STRIDE + 2 * (size_t)BC * ROW_STRIDE;
     if (lds > 160 * 1024) return hipErrorInvalidValue;

@@ -117,12 +117,17 @@ __device__ __forceinline__ void store4_f32_or_bf16(float* base, size_t i, float4
     else *reinterpret_cast<uint2*>(reinterpret_cast<char*>(base) + i * 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
 }
 
-// sum over the 16 lanes that share (lane >> 4)
+// Reductions over the 16 lanes that share (lane >> 4) (one DPP row), result in all of them: quad_perm [1,0,3,2], quad_perm
+// [2,3,0,1], row_half_mirror, row_mirror -- four VALU ops with a DPP operand, no ds_bpermute round trip through the LDS.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float reduce16(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v += dpp_row<0xB1>(v);
+    v += dpp_row<0x4E>(v);
+    v += dpp_row<0x141>(v);
+    v += dpp_row<0x140>(v);
     return v;
 }
 // reductions over the 4 lanes that share (lane & 15), result in all of them.  v_permlane32_swap exchanges the upper half
@@ -142,12 +147,14 @@ __device__ __forceinline__ float max_q(float v) {
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float max16(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1));
-    v = fmaxf(v, __shfl_xor(v, 2));
-    v = fmaxf(v, __shfl_xor(v, 4));
-    v = fmaxf(v, __shfl_xor(v, 8));
+    v = fmaxf(v, dpp_row<0xB1>(v));
+    v = fmaxf(v, dpp_row<0x4E>(v));
+    v = fmaxf(v, dpp_row<0x141>(v));
+    v = fmaxf(v, dpp_row<0x140>(v));
     return v;
 }
+// n / d for n * d < 2^32 and d >= 2, with m = floor(2^32 / d) + 1 computed on the host: one v_mul_hi_u32
+__device__ __forceinline__ int div_magic(int n, unsigned m) { return (int)__umulhi((unsigned)n, m); }
 
 // GroupNorm statistics slab: stats[(b * GN_SLOTS + slot) * groups * 2 + g * 2 + {0: sum, 1: sumsq}]
 __device__ __forceinline__ void gn_mean_rstd(const double* stats, int b, int g, int groups, double count,

@@ -34,6 +34,7 @@ struct ConvArgs {
     // completed by launch_conv
     int Ho, Wo, Hy, Wy, CinPad, PH, PW, NP, tiles_y, tiles_x;
     unsigned x0_bytes, x1_bytes, w_bytes;          // buffer-descriptor extents
+    unsigned m_ihiw, m_iw, m_phpw, m_pw;           // floor(2^32 / d) + 1 for d = IH*IW, IW, PH*PW, PW (div_magic)
 };
 
 // out = SiLU(GroupNorm(y2; stats, gn_gamma, gn_beta)) + LayerNorm_C(r; ln_gamma, ln_beta), channel-last [B][pix][C]
