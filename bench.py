@@ -61,16 +61,19 @@ def conv_flops(layer, frames, batch):
     return 2.0 * batch * frames * s * s * cin * cout * taps
 
 
-def conv_bytes(layer, frames, batch, mode):
-    """Algorithmic HBM bytes of one conv launch: fp32 input + fp32 output + packed weights (SURVEY 8d op-level definition)."""
+def conv_bytes(layer, frames, batch, mode, act='f32'):
+    """Algorithmic HBM bytes of one conv launch: input + output tensors in their storage type (fp32, or bf16 with bf16
+    activation storage) + packed weights (SURVEY 8d op-level definition)."""
     cin, cout, s, taps, kind = layer
     so = s // 2 if kind == 'down' else (2 * s if kind == 'up' else s)
     es = 2 if mode == 'bf16' else 4
-    return 4.0 * batch * frames * (s * s * cin + so * so * cout) + es * taps * cin * cout
+    ea = 2.0 if act == 'bf16' else 4.0
+    return ea * batch * frames * (s * s * cin + so * so * cout) + es * taps * cin * cout
 
 
-def time_conv_kernels(unet, frames, size, batch, mode, reps=5):
-    """Roofline leg: replays every conv_igemm launch shape of one forward standalone, HIP events on the launch stream."""
+def time_conv_kernels(unet, frames, size, batch, mode, act='f32', reps=5):
+    """Roofline leg: replays every conv_igemm launch shape of one forward standalone (tensors in the storage type the timed
+    region used), HIP events on the launch stream."""
     from video_diffusion_nnx_amd import ops
     dev = unet.device
     per_symbol = {}
@@ -79,6 +82,8 @@ def time_conv_kernels(unet, frames, size, batch, mode, reps=5):
         cin, cout, s, taps, kind = layer
         k = {9: 3, 1: 1, 16: 4}[taps]
         x = torch.randn(batch, frames, s, s, cin, device=dev)
+        if act == 'bf16':
+            x = x.to(torch.bfloat16)
         w = torch.randn(1, k, k, cin, cout, device=dev) / (taps * cin) ** 0.5
         pw = ops.pack_conv_weights(w, mode)
         bias = torch.zeros(cout, device=dev)
@@ -86,7 +91,7 @@ def time_conv_kernels(unet, frames, size, batch, mode, reps=5):
         stats_in.view(batch, 32, 8, 2)[:, 0, :, 1] = float(frames * s * s * cin // 8)     # unit variance statistics
         stats_out = ops.gn_stats_zeros(batch, 8, dev)
         gamma = torch.ones(cin, device=dev); beta = torch.zeros(cin, device=dev)
-        kwargs = dict(mode=mode, bias=bias)
+        kwargs = dict(mode=mode, bias=bias, y_bf16=(act == 'bf16'))
         if kind == 'c3':
             kwargs.update(k=3, out_stats=stats_out)
         elif kind == 'c3p':
@@ -106,10 +111,11 @@ def time_conv_kernels(unet, frames, size, batch, mode, reps=5):
         e1.synchronize()
         ms = e0.elapsed_time(e1) / reps
         mode_id = {'f32': 0, 'bf16': 1}[mode]                                              # rocprof prints the template arguments
-        sym = f'vdx::conv_igemm_kernel<{mode_id}, {64 if cout <= 64 else 128}, {2 if (cout <= 64 and kind == "down") else 4}>'
+        narrow = cout <= 64 and kind == 'down'                                           # launch_conv: TN = 2 / 4 waves; else 8 waves x TN 2
+        sym = f'vdx::conv_igemm_kernel<{mode_id}, {64 if cout <= 64 else 128}, 2, {4 if narrow else 8}>'
         launches = 4 if kind == 'up' else 1                                              # the 4 phases are one launch (grid.z)
         d = per_symbol.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-        d['ms'] += ms; d['flops'] += conv_flops(layer, frames, batch); d['bytes'] += conv_bytes(layer, frames, batch, mode); d['launches'] += 1
+        d['ms'] += ms; d['flops'] += conv_flops(layer, frames, batch); d['bytes'] += conv_bytes(layer, frames, batch, mode, act); d['launches'] += 1
         del x, w, pw
     return per_symbol
 
@@ -225,7 +231,7 @@ def main():
     if rank == 0 and not args.no_roofline:
         log('roofline leg: replaying conv_igemm launch shapes ...')
         with torch.cuda.stream(stream):
-            per = time_conv_kernels(unet, Fr, S, B, args.mode)
+            per = time_conv_kernels(unet, Fr, S, B, args.mode, act)
         sym, d = max(per.items(), key=lambda kv: kv[1]['ms'])
         tflops = d['flops'] / (d['ms'] * 1e-3) / 1e12
         gbs = d['bytes'] / (d['ms'] * 1e-3) / 1e9
@@ -236,7 +242,8 @@ def main():
         tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get('batch') == B and tj.get('mode') == args.mode and tj.get('dim') == args.dim and sym in tj.get('kernels', {}):
+            if (tj.get('batch') == B and tj.get('mode') == args.mode and tj.get('dim') == args.dim and tj.get('act', 'f32') == act
+                    and sym in tj.get('kernels', {})):
                 traffic = tj['kernels'][sym]['hbm_bytes_per_launch']
         line['roofline'] = {'bound': 'hbm' if hbm_bound else 'mfma',
                             'achieved': gbs if hbm_bound else tflops, 'peak': HBM_PEAK_GBS if hbm_bound else mfma_peak,

@@ -74,6 +74,9 @@ typedef struct {
     const float* scale_shift; int scale_shift_stride;   /* rows [scale(c0) | shift(c0)] per sample, or NULL */
     /* optional epilogue: accumulate GroupNorm partial statistics of y into out_stats (pre-zeroed) */
     double* out_stats; int out_groups;
+    /* storage of the activation tensors (VDX_MODE_BF16 only): nonzero = the tensor holds bf16 elements instead of fp32 */
+    int x_bf16;                     /* x0 and x1 */
+    int y_bf16;
 } vdx_conv_desc;
 
 /* nnx.Conv / nnx.ConvTranspose on channel-last video (reference: modules.py:162-179 Block.proj + norm

@@ -3,18 +3,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from video_diffusion_nnx_amd.unet3d import Unet3D
 from video_diffusion_nnx_amd import ops
-B, Fr, S, mode = 8, 16, 64, 'bf16'
+B, Fr, S, mode = int(os.environ.get('CONVPROF_B', 8)), 16, 64, 'bf16'
+ACT16 = os.environ.get('CONVPROF_ACT', 'bf16') == 'bf16'      # bf16 activation storage: bf16 tensors in and out
 dev = torch.device('cuda:0')
 seen = {}
 for layer in bench.conv_layers(64, (1,2,4,8), Fr, S, B):
     if layer in seen: seen[layer][1] += 1; continue
     cin, cout, s, taps, kind = layer
     k = {9: 3, 1: 1, 16: 4}[taps]
-    x = torch.randn(B, Fr, s, s, cin, device=dev); w = torch.randn(1, k, k, cin, cout, device=dev) / (taps*cin)**0.5
+    x = torch.randn(B, Fr, s, s, cin, device=dev)
+    if ACT16: x = x.to(torch.bfloat16)
+    w = torch.randn(1, k, k, cin, cout, device=dev) / (taps*cin)**0.5
     pw = ops.pack_conv_weights(w, mode); bias = torch.zeros(cout, device=dev)
     so = ops.gn_stats_zeros(B, 8, dev); si = ops.gn_stats_zeros(B, 8, dev); si.view(B,32,8,2)[:,0,:,1] = float(Fr*s*s*cin//8)
     g = torch.ones(cin, device=dev); be = torch.zeros(cin, device=dev)
-    kw = dict(mode=mode, bias=bias)
+    kw = dict(mode=mode, bias=bias, y_bf16=ACT16)
     if kind == 'c3': kw.update(k=3, out_stats=so)
     elif kind == 'c3p': kw.update(k=3, in_stats=si, gamma=g, beta=be, out_stats=so)
     elif kind == 'c1': kw.update(k=1)

@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ('in_stats', c_void_p), ('gamma', c_void_p), ('beta', c_void_p), ('groups', c_int),
         ('scale_shift', c_void_p), ('scale_shift_stride', c_int),
         ('out_stats', c_void_p), ('out_groups', c_int),
+        ('x_bf16', c_int), ('y_bf16', c_int),
     ]
 
 

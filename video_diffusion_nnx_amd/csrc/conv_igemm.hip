@@ -25,7 +25,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned OOB = 0xFFFFFFF0u;      // buffer-load offset beyond num_records: the hardware returns zeros
 
-// TN = 16-pixel tiles per wave (4: 64 pixels, 2: 32 pixels).  Workgroup tile = BC channels x BM pixels.
+// TN = 16-pixel tiles per wave (4: 64 pixels, 2: 32 pixels), NW = waves.  Workgroup tile = BC channels x BM pixels.
 template <int MODE, int BC, int TN, int NW>
 __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
     using M = Mma<MODE>;
@@ -434,7 +434,9 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     a.x0_bytes = (unsigned)b0; a.x1_bytes = (unsigned)b1; a.w_bytes = (unsigned)bw;
     // variant: 64-channel tiles take 256 pixels per workgroup (stride 1) so every wave owns a 64x64 tile
     const int BC = a.Cout <= 64 ? 64 : 128;
-    static const int nw8 = getenv("VDX_CONV_NW8") ? atoi(getenv("VDX_CONV_NW8")) : 0;     // experiment: 8-wave workgroups, same tile
+    // 8-wave workgroups (each wave 32 pixels x 64 channels of the same workgroup tile): 4 waves per SIMD instead of 2;
+    // VDX_CONV_NW8=0 selects the 4-wave form (64 x 64 per wave) for comparison
+    static const int nw8 = getenv("VDX_CONV_NW8") ? atoi(getenv("VDX_CONV_NW8")) : 1;
     const int TN = (BC == 64 && a.stride == 2) ? 2 : 4;
     const int BM = 16 * TN * (4 / (BC / 64));
     choose_patch(BM, a.NF, a.F, a.Ho, a.Wo, a.stride, K, a.PH, a.PW, a.NP);

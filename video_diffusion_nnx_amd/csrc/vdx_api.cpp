@@ -72,6 +72,9 @@ int vdx_conv_forward(int mode, const vdx_conv_desc* d, void* stream) {
         if (d->out_groups <= 0 || d->cout % d->out_groups) VDX_FAIL(VDX_ERR_INVALID, "conv: bad out_groups");
         a.out_stats = d->out_stats; a.out_groups = d->out_groups;
     }
+    if ((d->x_bf16 || d->y_bf16) && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "conv: bf16 tensors need VDX_MODE_BF16");
+    if (d->x_bf16 && (d->c0 % 8 || d->c1 % 8)) VDX_FAIL(VDX_ERR_INVALID, "conv: bf16 inputs need channel counts that are multiples of 8");
+    a.x0_bf16 = a.x1_bf16 = d->x_bf16 ? 1 : 0; a.y_bf16 = d->y_bf16 ? 1 : 0;
     VDX_HIP(vdx::launch_conv(mode, a, (hipStream_t)stream));
     return VDX_OK;
 }

@@ -36,16 +36,20 @@ def gn_stats_reduce(stats: torch.Tensor, batch: int, groups: int) -> torch.Tenso
 
 def conv_forward(x0, packed_w, cout, *, mode, bias=None, x1=None, kind=0, k=3, stride=1,
                  in_stats=None, gamma=None, beta=None, groups=8, scale_shift=None,
-                 out_stats=None, out_groups=8) -> torch.Tensor:
-    """x0: [B,F,H,W,C0] channel-last fp32 (x1 likewise, concatenated on channels)."""
+                 out_stats=None, out_groups=8, y_bf16=False) -> torch.Tensor:
+    """x0: [B,F,H,W,C0] channel-last fp32 -- or bf16 (bf16 mode: bf16 activation storage) -- (x1 likewise, concatenated on
+    channels); y_bf16 selects a bf16 output tensor."""
     B, Fr, H, W, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[-1]
     if kind == 1:
         Ho, Wo = 2 * H, 2 * W
     else:
         Ho, Wo = -(-H // stride), -(-W // stride)
-    y = torch.empty(B, Fr, Ho, Wo, cout, dtype=torch.float32, device=x0.device)
+    x_bf16 = x0.dtype == torch.bfloat16
+    assert x0.dtype in (torch.float32, torch.bfloat16) and (x1 is None or x1.dtype == x0.dtype)
+    y = torch.empty(B, Fr, Ho, Wo, cout, dtype=torch.bfloat16 if y_bf16 else torch.float32, device=x0.device)
     d = L.ConvDesc()
+    d.x_bf16, d.y_bf16 = int(x_bf16), int(bool(y_bf16))
     d.x0, d.x1, d.c0, d.c1 = L.ptr(x0), L.ptr(x1), c0, c1
     d.packed_w, d.bias, d.y, d.cout = L.ptr(packed_w), L.ptr(bias), L.ptr(y), cout
     d.batch, d.frames, d.h, d.w = B, Fr, H, W
