@@ -234,6 +234,8 @@ typedef struct {
     int kind, kh, kw, stride;                          /* as vdx_conv_desc */
     const double* in_stats; const float* gamma; const float* beta; int groups;     /* optional fused prologue of the forward */
     const float* scale_shift; int scale_shift_stride;
+    int bf16_operands;                                 /* 0: exact-f32 MFMA; 1: operands rounded to bf16, fp32 accumulate (what a
+                                                          VDX_MODE_BF16 handle's backward uses) */
 } vdx_wgrad_desc;
 
 /* dW += Xhat^T (*) dY on exact-f32 MFMA (both arithmetic modes use it). */

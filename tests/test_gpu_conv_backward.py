@@ -63,7 +63,10 @@ def test_conv_dgrad_wgrad_bias(mode, case):
     assert dx.shape == gx.shape
     assert _rel(dx.cpu().double(), gx) < tol, (mode, case, _rel(dx.cpu().double(), gx))
     dw = ops.conv_backward_weights(x.detach().float().to(DEV), dyd, kern.shape, kind=kind, k=k, stride=stride)
-    assert _rel(dw.cpu().double(), gk) < 5e-6, (case, _rel(dw.cpu().double(), gk))      # exact-f32 MFMA in both modes
+    assert _rel(dw.cpu().double(), gk) < 5e-6, (case, _rel(dw.cpu().double(), gk))      # exact-f32 MFMA form
+    if mode == 'bf16':     # the form a bf16-mode handle's backward uses: operands rounded to bf16 (transposing LDS reads), fp32 accumulate
+        dw16 = ops.conv_backward_weights(x.detach().float().to(DEV), dyd, kern.shape, kind=kind, k=k, stride=stride, bf16_operands=True)
+        assert _rel(dw16.cpu().double(), gk) < 8e-3, (case, _rel(dw16.cpu().double(), gk))
     db = ops.colsum(dyd)
     assert _rel(db.cpu().double(), gb) < 5e-6
 
@@ -95,6 +98,12 @@ def test_wgrad_concat_and_prologue():
     dw2 = ops.conv_backward_weights(y1.float().to(DEV), dy2.float().to(DEV), k2.shape, in_stats=stats.reshape(-1).to(DEV),
                                     gamma=gamma.float().to(DEV), beta=beta.float().to(DEV), scale_shift=ss.float().to(DEV))
     assert _rel(dw2.cpu().double(), gk2) < 2e-5
+    # bf16-operand form of both
+    dw16 = ops.conv_backward_weights(xa.float().to(DEV), dy.float().to(DEV), kern.shape, x1=xb.float().to(DEV), bf16_operands=True)
+    assert _rel(dw16.cpu().double(), gk) < 8e-3
+    dw216 = ops.conv_backward_weights(y1.float().to(DEV), dy2.float().to(DEV), k2.shape, in_stats=stats.reshape(-1).to(DEV),
+                                      gamma=gamma.float().to(DEV), beta=beta.float().to(DEV), scale_shift=ss.float().to(DEV), bf16_operands=True)
+    assert _rel(dw216.cpu().double(), gk2) < 8e-3
 
 
 @pytest.mark.parametrize('C,B,shape,use_ss,tail', [(16, 2, (3, 5, 5), True, False), (64, 2, (4, 8, 8), True, False), (64, 1, (2, 8, 8), False, True),

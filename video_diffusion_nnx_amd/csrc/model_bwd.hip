@@ -53,6 +53,7 @@ void wgrad(Bwd& b, const float* x0, int c0, const float* x1, int c1, const float
     a.x0 = x0; a.x1 = x1; a.C0 = c0; a.C1 = c1; a.dy = dy; a.Cout = Cout; a.dW = b.grads + w_off; a.db = b_off >= 0 ? b.grads + b_off : nullptr;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl_in);
     a.kind = kind; a.kh = a.kw = kind ? 4 : k; a.stride = kind ? 1 : stride;
+    a.bf16_mma = (b.m->mode == MODE_BF16);
     if (in_stats) { a.x0_bf16 = (b.m->mode == MODE_BF16); a.pro = 1; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta; a.groups = b.m->cfg.resnet_groups; a.ss = ss; a.ss_stride = ss_stride; }
     b.ok(launch_conv_wgrad(a, b.st));
 }
@@ -118,6 +119,7 @@ void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w
     a.x0 = x; a.C0 = cin; a.dy = dy; a.Cout = cout; a.dW = b.grads + w_off; a.db = b_off >= 0 ? b.grads + b_off : nullptr;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
+    a.bf16_mma = (b.m->mode == MODE_BF16);
     b.ok(launch_conv_wgrad(a, b.st));
 }
 

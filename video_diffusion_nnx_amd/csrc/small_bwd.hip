@@ -99,10 +99,8 @@ __global__ __launch_bounds__(256) void resblock_ss_bwd_kernel(const float* __res
     const int tid = threadIdx.x;
     const SsLayer L = layers[blockIdx.x];
     const int N = L.n;
-    for (int i = tid; i < B * temb_dim; i += 256) act[i] = silu_f(temb[i]);
-    const float* W = params + L.w_off;
     const float* g = params + L.g_off;
-    float* dW = grads + L.w_off; float* db = grads + L.b_off; float* dg = grads + L.g_off; float* dbe = grads + L.be_off;
+    float* db = grads + L.b_off; float* dg = grads + L.g_off; float* dbe = grads + L.be_off;
     const float* lin = lin_base + (size_t)L.out_off * B;
     float* dss = dss_base + (size_t)L.out_off * B;
     // LayerNorm backward per sample (in place: dss <- dlin), parameter gradients accumulated over samples
@@ -134,20 +132,40 @@ __global__ __launch_bounds__(256) void resblock_ss_bwd_kernel(const float* __res
         }
         __syncthreads();
     }
-    // dW[k][n] += sum_b act[b][k] dlin[b][n]
-    for (int n = tid; n < N; n += 256)
-        for (int k = 0; k < temb_dim; ++k) {
+}
+
+// second half of the time-MLP backward, parallel over (layer, KB rows of the Linear): with dlin from the kernel above
+//   dW[k][n] += sum_b SiLU(temb[b][k]) dlin[b][n]          (coalesced over n)
+//   dtemb[b][k] += SiLU'(temb[b][k]) sum_n dlin[b][n] W[k][n]   (workgroup reduction over n, one atomic per (b, k))
+constexpr int SS_KB = 8;
+__global__ __launch_bounds__(256) void resblock_ss_bwd_w_kernel(const float* __restrict__ params, float* __restrict__ grads, const float* __restrict__ temb,
+                                                                const SsLayer* __restrict__ layers, const float* __restrict__ dss_base,
+                                                                float* __restrict__ dtemb, int temb_dim, int B) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x;
+    const SsLayer L = layers[blockIdx.x];
+    const int N = L.n;
+    const float* W = params + L.w_off;
+    float* dW = grads + L.w_off;
+    const float* dlin = dss_base + (size_t)L.out_off * B;
+    for (int kk = 0; kk < SS_KB; ++kk) {
+        const int k = blockIdx.y * SS_KB + kk;
+        if (k >= temb_dim) break;
+        for (int n = tid; n < N; n += 256) {
             float acc = 0.f;
-            for (int b = 0; b < B; ++b) acc = fmaf(act[(size_t)b * temb_dim + k], dss[(size_t)b * N + n], acc);
-            dW[(size_t)k * N + n] += acc;
+            for (int b = 0; b < B; ++b) acc = fmaf(silu_f(temb[(size_t)b * temb_dim + k]), dlin[(size_t)b * N + n], acc);
+            dW[(size_t)k * N + n] += acc;                       // this workgroup owns rows k of this layer: no atomics
         }
-    // dtemb[b][k] += silu'(temb) * sum_n dlin[b][n] W[k][n]
-    for (int k = tid; k < temb_dim; k += 256)
         for (int b = 0; b < B; ++b) {
             float acc = 0.f;
-            for (int n = 0; n < N; ++n) acc = fmaf(dss[(size_t)b * N + n], W[(size_t)k * N + n], acc);
-            atomicAdd(dtemb + (size_t)b * temb_dim + k, acc * dsilu2_f(temb[(size_t)b * temb_dim + k]));
+            for (int n = tid; n < N; n += 256) acc = fmaf(dlin[(size_t)b * N + n], W[(size_t)k * N + n], acc);
+            for (int o = 1; o < 64; o <<= 1) acc += __shfl_xor(acc, o);
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = acc;
+            __syncthreads();
+            if (tid == 0) atomicAdd(dtemb + (size_t)b * temb_dim + k, (red[0] + red[1] + red[2] + red[3]) * dsilu2_f(temb[(size_t)b * temb_dim + k]));
         }
+    }
 }
 
 __device__ __forceinline__ float gelu_tanh_b(float x) {
@@ -228,6 +246,10 @@ hipError_t launch_resblock_ss_bwd(const float* params, float* grads, const float
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kfn, dim3(nlayers), dim3(256), lds, st, params, grads, temb, layers, lin_base, dss_base, dtemb, temb_dim, B);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(resblock_ss_bwd_w_kernel, dim3(nlayers, (temb_dim + SS_KB - 1) / SS_KB), dim3(256), 0, st, params, grads, temb, layers,
+                       dss_base, dtemb, temb_dim, B);
     return hipGetLastError();
 }
 

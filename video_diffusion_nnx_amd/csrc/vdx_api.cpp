@@ -360,6 +360,7 @@ int vdx_conv_backward_weights(const vdx_wgrad_desc* d, void* stream) {
         if (d->c1 || !d->gamma || !d->beta || d->groups <= 0 || d->groups > 32) VDX_FAIL(VDX_ERR_INVALID, "wgrad: bad prologue");
         a.pro = 1; a.in_stats = d->in_stats; a.gamma = d->gamma; a.beta = d->beta; a.groups = d->groups; a.ss = d->scale_shift; a.ss_stride = d->scale_shift_stride;
     }
+    a.bf16_mma = d->bf16_operands ? 1 : 0;
     VDX_HIP(vdx::launch_conv_wgrad(a, (hipStream_t)stream));
     return VDX_OK;
 }

@@ -128,6 +128,7 @@ struct WgradArgs {
     int kind, kh, kw, stride;
     int pro; const double* in_stats; const float* gamma; const float* beta; int groups; const float* ss; int ss_stride;
     int x0_bf16;                                           // x0 stored as bf16
+    int bf16_mma;                                          // bf16 MFMA operands (bf16 mode) instead of exact f32
     // completed by the launcher
     int taps, sa, sb, ext, halo, Hm, Wm, Hy, Wy, PH, PW, co_tiles;
 };

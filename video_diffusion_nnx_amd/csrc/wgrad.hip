@@ -162,6 +162,182 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
     }
 }
 
+// ---- bf16 form (bf16 mode) -------------------------------------------------------------------------------------------
+// Same tiling, but both operands are rounded to bf16 while staged (like every other contraction of bf16 mode) into natural
+// [pixel][64 channels] bf16 LDS images, and the K-strided fragments come from gfx950's transposing LDS read:
+// ds_read_b64_tr_b16 gives lane i of a 16-lane group column i of a 4-row x 16-column block, every lane supplying its own
+// row address -- so the 4 rows are 4 consecutive patch positions (not contiguous in the halo tile) and the result is the
+// 4 consecutive-K elements of channel i that v_mfma_f32_16x16x32_bf16 wants (two reads per 32-deep operand).
+// One MFMA covers 32 positions where the f32 form needs 8 (16x16x4, 4 per step at twice the cycles): the kernel becomes
+// staging-bound.  Bias column sums are taken from the fp32 values while staging (exact).
+typedef short s16x4t __attribute__((ext_vector_type(4)));
+constexpr int WG_RSB = 64 * 2 + 16;         // bytes per LDS pixel row of the bf16 images
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* row0, const char* row1) {
+    const s16x4t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4t*)(uintptr_t)(unsigned)(uintptr_t)row0);
+    const s16x4t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4t*)(uintptr_t)(unsigned)(uintptr_t)row1);
+    typedef short s16x8t __attribute__((ext_vector_type(8)));
+    const s16x8t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int wi = w & 1, wo = w >> 1;
+    const int ci0 = blockIdx.y * 64, co0 = (blockIdx.z % P.co_tiles) * 64;
+    const int tap0 = (blockIdx.z / P.co_tiles) * NT;
+    const int Cin = P.C0 + P.C1;
+    const int IH = (P.PH - 1) * P.sa + P.ext, IW = (P.PW - 1) * P.sa + P.ext;
+    const int BH = P.PH * P.sb, BW = P.PW * P.sb;
+    const int HPX = IH * IW, BPX = BH * BW;
+
+    char* As = smem;                                         // [HPX][WG_RSB] bf16
+    char* Bs = As + (size_t)HPX * WG_RSB;                    // [BPX][WG_RSB] bf16
+    float* coefA = reinterpret_cast<float*>(Bs + (size_t)BPX * WG_RSB);
+    float* coefD = coefA + 64;
+    float* gm = coefD + 64;
+    float* bsum = gm + 64;                                   // [64] bias column sums of this workgroup
+    int* tapA = reinterpret_cast<int*>(bsum + 64);           // [NT] byte offsets of the tap shift in As / Bs
+    int* tapB = tapA + 16;
+
+    if (tid < NT) {
+        const int t = tap0 + tid;
+        int ay, ax, by = 0, bx = 0;
+        if (P.kind == 0) { ay = t / P.kw; ax = t % P.kw; }
+        else { const int jy = t >> 2, jx = t & 3; ay = (jy >> 1) + (jy & 1); ax = (jx >> 1) + (jx & 1); by = jy & 1; bx = jx & 1; }
+        tapA[tid] = (ay * IW + ax) * WG_RSB;
+        tapB[tid] = (by * BW + bx) * WG_RSB;
+    }
+    if (tid < 64) bsum[tid] = 0.f;
+
+    f32x4 acc[NT][2][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc[t][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int tiles_x = (P.Wm + P.PW - 1) / P.PW, tiles_y = (P.Hm + P.PH - 1) / P.PH;
+    const int patches_per_frame = tiles_x * tiles_y;
+    const long total_patches = (long)P.NF * patches_per_frame;
+    int last_b = -1;
+    const bool do_bias = P.db && (blockIdx.y == 0) && (blockIdx.z / P.co_tiles == 0);
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);         // this thread's 4 channels (i & 15 is constant per thread)
+    // transposing-read lane roles: group g = q supplies positions 8g..8g+7 of a 32-position K block; inside the group lane
+    // 4*qr + pc supplies row qr (and qr + 4 for the second read), 8-byte column chunk pc
+    const int qr = r >> 2, pcz = r & 3;
+    for (long pid = blockIdx.x; pid < total_patches; pid += gridDim.x) {
+        const int f = (int)(pid / patches_per_frame);
+        const int pr = (int)(pid % patches_per_frame);
+        const int ty = pr / tiles_x, tx = pr % tiles_x;
+        const int my0 = ty * P.PH, mx0 = tx * P.PW;
+        const int iy0 = my0 * P.sa - P.halo, ix0 = mx0 * P.sa - P.halo;
+        const int b = f / P.F;
+        __syncthreads();                                      // previous patch fully consumed
+        if (P.pro && b != last_b) {
+            if (tid < P.groups) {
+                float m, rs;
+                gn_mean_rstd(P.in_stats, b, tid, P.groups, (double)P.F * P.H * P.W * (Cin / P.groups), m, rs);
+                gm[2 * tid] = m; gm[2 * tid + 1] = rs;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                const int c = ci0 + tid;
+                float a = 0.f, d = 0.f;
+                if (c < Cin) {
+                    const int g = c / (Cin / P.groups);
+                    const float ga = P.gamma[c], be = P.beta[c];
+                    float sc = 1.f, sh = 0.f;
+                    if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + c] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + Cin + c]; }
+                    a = gm[2 * g + 1] * ga * sc;
+                    d = (be - gm[2 * g] * gm[2 * g + 1] * ga) * sc + sh;
+                }
+                coefA[tid] = a; coefD[tid] = d;
+            }
+            last_b = b;
+            __syncthreads();
+        }
+        for (int i = tid; i < HPX * 16; i += 256) {
+            const int hp = i >> 4, pc = i & 15;
+            const int iy = hp / IW, ix = hp - iy * IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            const int c = ci0 + pc * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin) {
+                const size_t pix = ((size_t)f * P.H + gy) * P.W + gx;
+                v = (c < P.C0) ? load4_f32_or_bf16(P.x0, pix * P.C0 + c, P.x0_bf16)
+                               : *reinterpret_cast<const float4*>(P.x1 + pix * P.C1 + (c - P.C0));
+                if (P.pro) {
+                    const float4 a = *reinterpret_cast<const float4*>(coefA + pc * 4);
+                    const float4 d = *reinterpret_cast<const float4*>(coefD + pc * 4);
+                    v.x = silu_f(fmaf(v.x, a.x, d.x)); v.y = silu_f(fmaf(v.y, a.y, d.y));
+                    v.z = silu_f(fmaf(v.z, a.z, d.z)); v.w = silu_f(fmaf(v.w, a.w, d.w));
+                }
+            }
+            *reinterpret_cast<uint2*>(As + (size_t)hp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        }
+        for (int i = tid; i < BPX * 16; i += 256) {
+            const int bp = i >> 4, pc = i & 15;
+            const int yy = bp / BW, xx = bp - yy * BW;
+            const int gy = my0 * P.sb + yy, gx = mx0 * P.sb + xx;
+            const int c = co0 + pc * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy < P.Hy && gx < P.Wy && c < P.Cout) v = *reinterpret_cast<const float4*>(P.dy + (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c);
+            bias4.x += v.x; bias4.y += v.y; bias4.z += v.z; bias4.w += v.w;
+            *reinterpret_cast<uint2*>(Bs + (size_t)bp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        }
+        __syncthreads();
+        // ---- K loop: 32 patch positions per MFMA (PW == 8: one 8-position patch row per lane group) ----
+        const int npos = P.PH * P.PW;
+        for (int k0 = 0; k0 < npos; k0 += 32) {
+            const int p0 = k0 + 8 * q + qr, p1 = p0 + 4;
+            const int py0 = p0 >> 3, px0 = p0 & 7, py1 = p1 >> 3, px1 = p1 & 7;
+            const char* a0 = As + (size_t)((py0 * P.sa) * IW + px0 * P.sa) * WG_RSB + wi * 64 + pcz * 8;
+            const char* a1 = As + (size_t)((py1 * P.sa) * IW + px1 * P.sa) * WG_RSB + wi * 64 + pcz * 8;
+            const char* b0 = Bs + (size_t)((py0 * P.sb) * BW + px0 * P.sb) * WG_RSB + wo * 64 + pcz * 8;
+            const char* b1 = Bs + (size_t)((py1 * P.sb) * BW + px1 * P.sb) * WG_RSB + wo * 64 + pcz * 8;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 af0 = tr_frag(a0 + tapA[t], a1 + tapA[t]);
+                const bf16x8 af1 = tr_frag(a0 + tapA[t] + 32, a1 + tapA[t] + 32);
+                const bf16x8 bf0 = tr_frag(b0 + tapB[t], b1 + tapB[t]);
+                const bf16x8 bf1 = tr_frag(b0 + tapB[t] + 32, b1 + tapB[t] + 32);
+                acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[t][0][0], 0, 0, 0);
+                acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[t][0][1], 0, 0, 0);
+                acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[t][1][0], 0, 0, 0);
+                acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc[t][1][1], 0, 0, 0);
+            }
+        }
+    }
+    if (do_bias) {
+        const int pc = tid & 15;
+        atomicAdd(&bsum[pc * 4 + 0], bias4.x); atomicAdd(&bsum[pc * 4 + 1], bias4.y);
+        atomicAdd(&bsum[pc * 4 + 2], bias4.z); atomicAdd(&bsum[pc * 4 + 3], bias4.w);
+        __syncthreads();
+        if (tid < 64 && co0 + tid < P.Cout) atomicAdd(P.db + co0 + tid, bsum[tid]);
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int tap = tap0 + t;
+        if (tap >= P.taps) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = co0 + wo * 32 + j * 16 + r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = ci0 + wi * 32 + i * 16 + 4 * q + e;
+                    if (ci < Cin && co < P.Cout) atomicAdd(P.dW + ((size_t)tap * Cin + ci) * P.Cout + co, acc[t][i][j][e]);
+                }
+            }
+    }
+}
+
 // out[c] += sum over rows of x[row][c]   (bias / LayerNorm-beta gradients); x is [rows][C] fp32
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int C) {
     __shared__ float red[256];
@@ -222,6 +398,15 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
     const long tiles = (long)ci_tiles * a.co_tiles * tap_groups;
     long chunks = std::max<long>(1, std::min<long>(patches, 1024 / std::max<long>(1, tiles)));
     dim3 grid((unsigned)chunks, ci_tiles, a.co_tiles * tap_groups);
+    if (a.bf16_mma && a.PW == 8) {
+        const size_t lds16 = ((size_t)IH * IW + (size_t)a.PH * a.sb * a.PW * a.sb) * WG_RSB + 4 * 64 * 4 + 32 * 4;
+#define VDX_WG16(NT_) do { auto kfn = conv_wgrad16_kernel<NT_>;                                                       \
+        if (lds16 > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16); if (e != hipSuccess) return e; } \
+        hipLaunchKernelGGL(kfn, grid, dim3(256), lds16, st, a); } while (0)
+        if (NT == 1) VDX_WG16(1); else if (NT == 9) VDX_WG16(9); else VDX_WG16(8);
+#undef VDX_WG16
+        return hipGetLastError();
+    }
 #define VDX_WG(NT_) do { auto kfn = conv_wgrad_kernel<NT_>;                                                           \
         if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a); } while (0)

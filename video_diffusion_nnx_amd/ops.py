@@ -137,7 +137,7 @@ class WgradDesc(C.Structure):
                 ('dw', C.c_void_p), ('batch', C.c_int), ('frames', C.c_int), ('h', C.c_int), ('w', C.c_int),
                 ('kind', C.c_int), ('kh', C.c_int), ('kw', C.c_int), ('stride', C.c_int),
                 ('in_stats', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('groups', C.c_int),
-                ('scale_shift', C.c_void_p), ('scale_shift_stride', C.c_int)]
+                ('scale_shift', C.c_void_p), ('scale_shift_stride', C.c_int), ('bf16_operands', C.c_int)]
 
 
 _pack_t = L._sig('vdx_pack_conv_weights_t', C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p])
@@ -156,7 +156,7 @@ def pack_conv_weights_t(kernel: torch.Tensor, mode) -> torch.Tensor:
 
 
 def conv_backward_weights(x0, dy, kshape, *, x1=None, kind=0, k=3, stride=1, in_stats=None, gamma=None, beta=None, groups=8,
-                          scale_shift=None, dw=None) -> torch.Tensor:
+                          scale_shift=None, dw=None, bf16_operands=False) -> torch.Tensor:
     B, Fr, H, W, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[-1]
     cout = dy.shape[-1]
@@ -169,6 +169,7 @@ def conv_backward_weights(x0, dy, kshape, *, x1=None, kind=0, k=3, stride=1, in_
     d.in_stats, d.gamma, d.beta, d.groups = L.ptr(in_stats), L.ptr(gamma), L.ptr(beta), groups
     d.scale_shift = L.ptr(scale_shift)
     d.scale_shift_stride = 0 if scale_shift is None else scale_shift.shape[-1]
+    d.bf16_operands = int(bool(bf16_operands))
     L.check(_wgrad(C.byref(d), L.stream_ptr()))
     return dw
 
