@@ -401,32 +401,61 @@ hipError_t launch_time_mlp(const TimeMlpArgs& a, int B, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-ResnetBlock scale/shift: ss[l][b] = LayerNorm_{2c}(Linear(SiLU(temb[b])))   grid (B, nlayers)
+// per-ResnetBlock scale/shift: ss[l][b] = LayerNorm_{2c}(Linear(SiLU(temb[b])))
+// Two launches: (1) the Linear, parallel over (layer, 64-column group, sample group): thread = (column, k quarter), 8 samples
+// per pass, the weight row read once for all of them, coalesced; (2) the LayerNorm per (sample, layer).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void resblock_ss_kernel(const float* __restrict__ params, const float* __restrict__ temb,
-                                                          const SsLayer* __restrict__ layers, float* __restrict__ ss_base,
-                                                          float* __restrict__ lin_base, int temb_dim, int B) {
-    extern __shared__ float sm[];                  // act[temb_dim] | red[16]
+constexpr int SS_BG = 8;                            // samples per workgroup of the Linear
+__global__ __launch_bounds__(256) void resblock_ss_lin_kernel(const float* __restrict__ params, const float* __restrict__ temb,
+                                                              const SsLayer* __restrict__ layers, float* __restrict__ lin_base,
+                                                              int temb_dim, int B) {
+    extern __shared__ float sm[];                  // act[SS_BG][temb_dim] | part[4][SS_BG][64]
     float* act = sm;
-    float* red = sm + temb_dim;
+    float* part = sm + SS_BG * temb_dim;
+    const SsLayer L = layers[blockIdx.x];
+    const int N = L.n, n0 = blockIdx.y * 64;
+    if (n0 >= N) return;                            // uniform: layers differ in width
+    const int b0 = blockIdx.z * SS_BG, nb = min(SS_BG, B - b0);
+    const int tid = threadIdx.x, col = tid & 63, kq = tid >> 6;
+    for (int i = tid; i < nb * temb_dim; i += 256) act[i] = silu_f(temb[(size_t)b0 * temb_dim + i]);
+    __syncthreads();
+    const int n = n0 + col;
+    const float* W = params + L.w_off;
+    float acc[SS_BG];
+#pragma unroll
+    for (int j = 0; j < SS_BG; ++j) acc[j] = 0.f;
+    const int kper = (temb_dim + 3) / 4, k0 = kq * kper, k1 = min(temb_dim, k0 + kper);
+    if (n < N)
+        for (int k = k0; k < k1; ++k) {
+            const float w = W[(size_t)k * N + n];
+#pragma unroll
+            for (int j = 0; j < SS_BG; ++j) acc[j] = fmaf(act[j * temb_dim + k], w, acc[j]);   // rows past nb hold stale LDS: never stored
+        }
+#pragma unroll
+    for (int j = 0; j < SS_BG; ++j) part[(kq * SS_BG + j) * 64 + col] = acc[j];
+    __syncthreads();
+    if (kq == 0 && n < N) {
+        const float bias = params[L.b_off + n];
+        for (int j = 0; j < nb; ++j)
+            lin_base[(size_t)L.out_off * B + (size_t)(b0 + j) * N + n] =
+                bias + part[(0 * SS_BG + j) * 64 + col] + part[(1 * SS_BG + j) * 64 + col] + part[(2 * SS_BG + j) * 64 + col] + part[(3 * SS_BG + j) * 64 + col];
+    }
+}
+
+__global__ __launch_bounds__(256) void resblock_ss_norm_kernel(const float* __restrict__ params, const SsLayer* __restrict__ layers,
+                                                               const float* __restrict__ lin_base, float* __restrict__ ss_base, int B) {
+    __shared__ float red[8];
     const int b = blockIdx.x, tid = threadIdx.x;
     const SsLayer L = layers[blockIdx.y];
-    for (int k = tid; k < temb_dim; k += 256) act[k] = silu_f(temb[(size_t)b * temb_dim + k]);
-    __syncthreads();
-    const float* W = params + L.w_off;
-    const float* bias = params + L.b_off;
     const int N = L.n;                              // 2 * cout  (<= 2048)
+    const float* lin = lin_base + (size_t)L.out_off * B + (size_t)b * N;
     float v[8];
     float s = 0.f, ss = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int n = tid + 256 * j;
-        v[j] = 0.f;
-        if (n < N) {
-            float acc = bias[n];
-            for (int k = 0; k < temb_dim; ++k) acc = fmaf(act[k], W[(size_t)k * N + n], acc);
-            v[j] = acc; s += acc; ss += acc * acc;
-        }
+        v[j] = (n < N) ? lin[n] : 0.f;
+        s += v[j]; ss += v[j] * v[j];
     }
     for (int o = 1; o < 64; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
     if ((tid & 63) == 0) { red[tid >> 6] = s; red[4 + (tid >> 6)] = ss; }
@@ -439,18 +468,23 @@ __global__ __launch_bounds__(256) void resblock_ss_kernel(const float* __restric
     const float* g = params + L.g_off;
     const float* be = params + L.be_off;
     float* out = ss_base + (size_t)L.out_off * B + (size_t)b * N;
-    float* lin = lin_base ? lin_base + (size_t)L.out_off * B + (size_t)b * N : nullptr;     // pre-LayerNorm values, kept for the backward
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int n = tid + 256 * j;
-        if (n < N) { out[n] = fmaf((v[j] - mean) * rstd, g[n], be[n]); if (lin) lin[n] = v[j]; }
+        if (n < N) out[n] = fmaf((v[j] - mean) * rstd, g[n], be[n]);
     }
 }
 
 hipError_t launch_resblock_ss(const float* params, const float* temb, const SsLayer* layers, int nlayers, float* ss_base,
-                              float* lin_base, int temb_dim, int B, hipStream_t st) {
-    hipLaunchKernelGGL(resblock_ss_kernel, dim3(B, nlayers), dim3(256), (size_t)(temb_dim + 16) * 4, st, params, temb, layers,
-                       ss_base, lin_base, temb_dim, B);
+                              float* lin_base, int temb_dim, int B, int max_n, hipStream_t st) {
+    // lin_base (the pre-LayerNorm values, also what the backward reads) is required scratch
+    if (!lin_base || nlayers <= 0) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)SS_BG * temb_dim + 4 * SS_BG * 64) * 4;
+    hipLaunchKernelGGL(resblock_ss_lin_kernel, dim3(nlayers, (max_n + 63) / 64, (B + SS_BG - 1) / SS_BG), dim3(256), lds, st, params, temb, layers,
+                       lin_base, temb_dim, B);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(resblock_ss_norm_kernel, dim3(B, nlayers), dim3(256), 0, st, params, layers, lin_base, ss_base, B);
     return hipGetLastError();
 }
 

@@ -451,7 +451,9 @@ int model_forward(const Model* m, const float* params, const void* packed, const
         t.dim = c.dim; t.time_dim = m->time_dim; t.cond = cond; t.null_cond_emb = c.cond_dim ? params + m->null_cond : nullptr;
         t.cond_mask = cond_mask; t.null_all = null_all; t.cond_dim = c.cond_dim; t.temb = f.temb; t.temb_dim = m->temb_dim;
         VDX_E(launch_time_mlp(t, B, st));
-        VDX_E(launch_resblock_ss(params, f.temb, m->d_ss_layers, (int)m->ss_layers.size(), f.ss, f.ss_lin, m->temb_dim, B, st));
+        int max_n = 0;
+        for (const SsLayer& l : m->ss_layers) max_n = std::max(max_n, l.n);
+        VDX_E(launch_resblock_ss(params, f.temb, m->d_ss_layers, (int)m->ss_layers.size(), f.ss, f.ss_lin, m->temb_dim, B, max_n, st));
     }
     // init conv + init temporal attention   (unet3d.py:280-286)
     VDX_E(launch_init_conv_mode(m->mode, x, params + m->init_w, params + m->init_b, f.slot(m->s_init), B, c.channels, Fr, S0, S0, m->init_dim, c.init_kernel_size, f.a16, st));

@@ -732,6 +732,13 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
     constexpr int NCHN = 64 / M::KC;
     constexpr int RSE = NCHN * 64 + 16;
     sla_plan(a.N, a.nsub, a.nchunk);
+    // the workspace is sized for that plan; with many frames longer chunks still fill the chip and halve the partial-context
+    // traffic (8 x 4.4 KB per chunk, written here and re-read by the combine) per doubling
+    {
+        const int tiles = (a.N + 63) / 64;
+        while (a.nsub * 2 <= tiles && (long)a.NF * ((tiles + 2 * a.nsub - 1) / (2 * a.nsub)) >= 1024) a.nsub *= 2;
+        a.nchunk = (tiles + a.nsub - 1) / a.nsub;
+    }
     const size_t part_bytes = (((size_t)a.NF * a.nchunk * a.heads * SLA_PART * 4) + 255) / 256 * 256;
     a.part = reinterpret_cast<float*>(a.workspace);
     a.ctxT = reinterpret_cast<char*>(a.workspace) + part_bytes;

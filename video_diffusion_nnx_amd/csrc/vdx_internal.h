@@ -67,7 +67,7 @@ hipError_t launch_init_conv_mode(int mode, const float* x, const float* w, const
 hipError_t launch_final_conv(const float* x, const float* w, const float* bias, float* y, long npix, int D, int Cout, int x_bf16, hipStream_t st);
 hipError_t launch_time_mlp(const TimeMlpArgs& a, int B, hipStream_t st);
 hipError_t launch_resblock_ss(const float* params, const float* temb, const SsLayer* layers, int nlayers, float* ss_base,
-                              float* lin_base, int temb_dim, int B, hipStream_t st);
+                              float* lin_base, int temb_dim, int B, int max_n, hipStream_t st);   // max_n = widest layer (2 * cout)
 
 // y = MHA(x) + x over sequences of L tokens; token address = (s / inner) * outer_stride + (s % inner) * inner_stride + tok * tok_stride
 struct AttnArgs {
