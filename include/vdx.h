@@ -255,6 +255,10 @@ int vdx_norm_act_backward(const float* dact, const float* y, float* dy, const do
  * [npix][heads*32].  temporal != 0: sequences over F per (b,h,w), else over (h w) per (b,f). */
 int vdx_attention_core_backward(const float* qkv, const float* d_o, float* o, float* dq, float* dk, float* dv, int batch, int frames,
                                 int h, int w, int heads, int temporal, void* stream);
+/* Same with a choice of arithmetic: bf16_operands != 0 = the form a VDX_MODE_BF16 handle's backward uses for sequences of <= 16
+ * tokens (q, k, v, d_o rounded to bf16, every product on MFMA, fp32 accumulate); 0 = exact fp32. */
+int vdx_attention_core_backward_ex(const float* qkv, const float* d_o, float* o, float* dq, float* dk, float* dv, int batch, int frames,
+                                   int h, int w, int heads, int temporal, int bf16_operands, void* stream);
 
 /* SpatialLinearAttention core backward (autodiff of modules.py:105-118 per frame and head; heads = 8, D = 32).
  * q, k, v, d_out [B*F*h*w][256]; writes o (pre to_out), dq, dk, dv.  scratch >= vdx_sla_backward_scratch_floats floats. */

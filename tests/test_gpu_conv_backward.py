@@ -169,6 +169,11 @@ def test_attention_core_backward(B, Fr, H, W, heads, temporal):
     assert _rel(og.cpu().double(), o_rows.detach()) < 1e-5
     got = torch.cat([dq, dk, dv], -1).cpu().double()
     assert _rel(got, gqkv) < 2e-5, _rel(got, gqkv)
+    # bf16-operand MFMA form (what a bf16-mode handle's backward runs for <= 16 tokens; longer sequences fall back to fp32)
+    og, dq, dk, dv = ops.attention_core_backward(qkv.detach().float().to(DEV), d_o.float().to(DEV), B, Fr, H, W, heads, temporal, bf16_operands=True)
+    tol = 1.5e-2 if (Fr if temporal else H * W) <= 16 else 2e-5
+    assert _rel(og.cpu().double(), o_rows.detach()) < tol
+    assert _rel(torch.cat([dq, dk, dv], -1).cpu().double(), gqkv) < tol
 
 
 @pytest.mark.parametrize('NF,H,W', [(2, 8, 8), (3, 5, 7), (1, 20, 20)])

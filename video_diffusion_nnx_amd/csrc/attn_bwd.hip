@@ -66,6 +66,127 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(AttnBwdArgs P) {
     }
 }
 
+// ---- bf16-mode form for sequences of <= 16 tokens: one wave per sequence, loop over heads, everything on MFMA ----------
+// Q (scaled), K, V, dO of one (sequence, head) are rounded to bf16 into four [16 tokens][32] LDS images (wave-private).
+//   S^T = K Q^T, S = Q K^T, dP^T = V dO^T, dP = dO V^T     four v_mfma_f32_16x16x32_bf16 on row reads of the images
+//   softmax / dS in both orientations (the accumulator of X^T is the B operand "K = row index of X^T" of a K=16 MFMA)
+//   O^T = V^T P^T, dV^T = dO^T P, dQ^T = K^T dS^T, dK^T = Q^T dS     A operands = ds_read_b64_tr_b16 of the images
+// so no score / probability ever goes through LDS, and each lane ends with 4 consecutive channels of one token: float4 stores.
+typedef short s16x4b __attribute__((ext_vector_type(4)));
+constexpr int AB_RS = 32 * 2 + 16;          // bytes per token row of an image
+
+__device__ __forceinline__ s16x4b tr_read4(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4b*)(uintptr_t)(unsigned)(uintptr_t)p);
+}
+__device__ __forceinline__ s16x4b pack4_bf16(const f32x4& v) {
+    const uint2 u = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    return __builtin_bit_cast(s16x4b, u);
+}
+
+__global__ __launch_bounds__(256) void attn_core_bwd16_kernel(AttnBwdArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 waves][4 images][16][AB_RS]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    char* img = smem + w * (4 * 16 * AB_RS);
+    char* Qi = img; char* Ki = Qi + 16 * AB_RS; char* Vi = Ki + 16 * AB_RS; char* Di = Vi + 16 * AB_RS;
+    const int HD = P.heads * 32;
+    const long s = (long)blockIdx.x * 4 + w;
+    const bool live = s < P.nseq;                            // a dead wave still runs (EXEC must stay full for the tr reads): it
+    const long sc = live ? s : 0;                            // recomputes sequence 0 and stores nothing
+    const long row0 = (sc / P.inner) * P.outer_p + (sc % P.inner);
+    // staging roles: lane -> (token row lr, 16-byte quarter pieces lq and lq + 4 of the 32 channels)
+    const int lr = lane >> 2, lq = lane & 3;
+    const bool rvalid = lr < P.L;
+    const size_t grow = (size_t)(row0 + (long)lr * P.tok_p);
+    // transposing-read roles: group q supplies token rows 4q..4q+3; in-group lane 4*qr + pc -> row 4q + qr, 8-byte chunk pc
+    const int troff = (4 * q + (lp >> 2)) * AB_RS + (lp & 3) * 8;
+    const size_t orow = (size_t)(row0 + (long)lp * P.tok_p);          // output: lane (token lp, q) writes channels 4q..4q+3 (+16)
+    const bool ovalid = live && lp < P.L;
+    const float L2E = 1.44269504088896f;
+    for (int h = 0; h < P.heads; ++h) {
+        // ---- stage the four images (wave-private: LDS ops of one wave stay in order) ----
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int c = (lq + 4 * u) * 4;
+            float4 vq = make_float4(0.f, 0.f, 0.f, 0.f), vk = vq, vv = vq, vd = vq;
+            if (rvalid) {
+                const float* src = P.qkv + grow * 3 * HD + h * 32 + c;
+                vq = *reinterpret_cast<const float4*>(src);
+                vk = *reinterpret_cast<const float4*>(src + HD);
+                vv = *reinterpret_cast<const float4*>(src + 2 * HD);
+                vd = *reinterpret_cast<const float4*>(P.dO + grow * HD + h * 32 + c);
+            }
+            *reinterpret_cast<uint2*>(Qi + lr * AB_RS + c * 2) = make_uint2(pack_bf16x2(vq.x * P.scale, vq.y * P.scale), pack_bf16x2(vq.z * P.scale, vq.w * P.scale));
+            *reinterpret_cast<uint2*>(Ki + lr * AB_RS + c * 2) = make_uint2(pack_bf16x2(vk.x, vk.y), pack_bf16x2(vk.z, vk.w));
+            *reinterpret_cast<uint2*>(Vi + lr * AB_RS + c * 2) = make_uint2(pack_bf16x2(vv.x, vv.y), pack_bf16x2(vv.z, vv.w));
+            *reinterpret_cast<uint2*>(Di + lr * AB_RS + c * 2) = make_uint2(pack_bf16x2(vd.x, vd.y), pack_bf16x2(vd.z, vd.w));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- scores and dP in both orientations (row reads: lane (r, q) = token r, channels 8q..8q+7) ----
+        const bf16x8 qf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Qi + lp * AB_RS + q * 16));
+        const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Ki + lp * AB_RS + q * 16));
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Vi + lp * AB_RS + q * 16));
+        const bf16x8 df = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Di + lp * AB_RS + q * 16));
+        const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 ST = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);    // lane (a = lp, q): keys b = 4q+e
+        f32x4 S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);     // lane (b = lp, q): queries a = 4q+e
+        f32x4 dPT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df, z, 0, 0, 0);   // dP^T[b][a]
+        f32x4 dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, z, 0, 0, 0);    // dP[a][b]
+        // ---- orientation "T": query a = lp, its keys in (q, e) ----
+        f32x4 PT, dST;
+        {
+            float mx = -1e30f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { if (4 * q + e >= P.L) ST[e] = -1e30f; mx = fmaxf(mx, ST[e]); }
+            mx = max_q(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { PT[e] = __builtin_amdgcn_exp2f((ST[e] - mx) * L2E); sum += PT[e]; }
+            const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
+            float dr = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { PT[e] *= inv; dr = fmaf(dPT[e], PT[e], dr); }
+            dr = reduce_q(dr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dST[e] = PT[e] * (dPT[e] - dr);
+        }
+        // ---- orientation "N": key b = lp, queries a = 4q+e: the row reductions run over the 16 lanes of a DPP row ----
+        f32x4 Pn, dSn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float sv = (lp >= P.L) ? -1e30f : S[e];
+            const float mx = max16(sv);
+            const float pe = __builtin_amdgcn_exp2f((sv - mx) * L2E);
+            const float pn = pe * __builtin_amdgcn_rcpf(reduce16(pe));
+            const float dr = reduce16(dP[e] * pn);
+            Pn[e] = pn; dSn[e] = pn * (dP[e] - dr);
+        }
+        const s16x4b bPT = pack4_bf16(PT), bdST = pack4_bf16(dST), bPn = pack4_bf16(Pn), bdSn = pack4_bf16(dSn);
+        // ---- O^T = V^T P^T, dV^T = dO^T P, dQ^T = K^T dS^T, dK^T = Q^T dS  (A = transposing read of an image, 16 channels per tile) ----
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const s16x4b av = tr_read4(Vi + troff + t * 32), ad = tr_read4(Di + troff + t * 32);
+            const s16x4b ak = tr_read4(Ki + troff + t * 32), aq = tr_read4(Qi + troff + t * 32);
+            const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bPT, z, 0, 0, 0);
+            const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ad, bPn, z, 0, 0, 0);
+            const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ak, bdST, z, 0, 0, 0);
+            const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aq, bdSn, z, 0, 0, 0);
+            if (ovalid) {
+                const size_t o_ = orow * HD + h * 32 + t * 16 + 4 * q;
+                *reinterpret_cast<float4*>(P.O + o_) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(P.dv + o_) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+                *reinterpret_cast<float4*>(P.dq + o_) = make_float4(dq[0] * P.scale, dq[1] * P.scale, dq[2] * P.scale, dq[3] * P.scale);
+                *reinterpret_cast<float4*>(P.dk + o_) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // images are rewritten for the next head
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 constexpr int SLA_A = 2 * 1024 + 96;     // floats per (frame, head): ctx | dctx | kmax | ksum | T
 
 // pass A: one workgroup per (frame, head): softmax-over-pixels statistics of k, ctx = ksm^T v, dctx = qsm^T dOut, T = sum_e dctx*ctx
@@ -198,6 +319,11 @@ __global__ __launch_bounds__(256) void sla_bwd_b_kernel(SlaBwdArgs P) {
 }
 
 hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st) {
+    if (a.bf16_mma && a.L <= 16) {
+        const long blocks = (a.nseq + 3) / 4;
+        hipLaunchKernelGGL(attn_core_bwd16_kernel, dim3((unsigned)blocks), dim3(256), 4 * 4 * 16 * AB_RS, st, a);
+        return hipGetLastError();
+    }
     const size_t lds = ((size_t)4 * a.L * 33 + 2 * a.L * (a.L + 1)) * 4;
     auto kfn = attn_core_bwd_kernel;
     if (lds > 64 * 1024) {

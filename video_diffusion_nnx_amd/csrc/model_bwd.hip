@@ -138,6 +138,7 @@ void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, 
     const long hw = (long)b.size(lvl) * b.size(lvl), Fr = m->cfg.num_frames;
     if (temporal) { a.L = (int)Fr; a.nseq = b.B * hw; a.inner = hw; a.outer_p = Fr * hw; a.tok_p = hw; }
     else { a.L = (int)hw; a.nseq = b.B * Fr; a.inner = 1; a.outer_p = hw; a.tok_p = 1; }
+    a.bf16_mma = (m->mode == MODE_BF16);
     b.ok(launch_attn_core_bwd(a, b.st));
     wgrad1x1(b, O, HD, g, C, ap.o_w, ap.o_b, lvl);
     float* d3[3] = {dq, dk, dv};

@@ -384,6 +384,11 @@ int vdx_norm_act_backward(const float* dact, const float* y, float* dy, const do
 
 int vdx_attention_core_backward(const float* qkv, const float* d_o, float* o, float* dq, float* dk, float* dv, int batch, int frames,
                                 int h, int w, int heads, int temporal, void* stream) {
+    return vdx_attention_core_backward_ex(qkv, d_o, o, dq, dk, dv, batch, frames, h, w, heads, temporal, 0, stream);
+}
+
+int vdx_attention_core_backward_ex(const float* qkv, const float* d_o, float* o, float* dq, float* dk, float* dv, int batch, int frames,
+                                   int h, int w, int heads, int temporal, int bf16_operands, void* stream) {
     if (!qkv || !d_o || !o || !dq || !dk || !dv || heads < 1) VDX_FAIL(VDX_ERR_INVALID, "attention_core_backward: bad argument");
     vdx::AttnBwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -392,6 +397,7 @@ int vdx_attention_core_backward(const float* qkv, const float* d_o, float* o, fl
     if (temporal) { a.L = frames; a.nseq = (long)batch * hw; a.inner = hw; a.outer_p = (long)frames * hw; a.tok_p = hw; }
     else { a.L = (int)hw; a.nseq = (long)batch * frames; a.inner = 1; a.outer_p = hw; a.tok_p = 1; }
     if (a.L > 64) VDX_FAIL(VDX_ERR_INVALID, "attention_core_backward: more than 64 tokens per sequence");
+    a.bf16_mma = bf16_operands ? 1 : 0;
     VDX_HIP(vdx::launch_attn_core_bwd(a, (hipStream_t)stream));
     return VDX_OK;
 }

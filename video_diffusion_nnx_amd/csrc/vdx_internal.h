@@ -155,6 +155,7 @@ hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st);
 struct AttnBwdArgs {
     const float* qkv; const float* dO; float* O; float* dq; float* dk; float* dv;
     int heads, L; long nseq, inner, outer_p, tok_p; float scale;
+    int bf16_mma;                                                    // bf16 MFMA form (bf16 mode, L <= 16) instead of the exact fp32 VALU form
 };
 hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st);
 // SLA core backward: q,k,v,dOut [NF*N][256] -> O (forward, pre to_out), dq, dk, dv ; A = scratch (sla_bwd_scratch_floats)

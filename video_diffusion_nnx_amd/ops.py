@@ -201,14 +201,15 @@ def norm_act_backward(dact, y, stats, gamma, beta, groups=8, scale_shift=None, r
     return out
 
 
-_attn_core_bwd = L._sig('vdx_attention_core_backward', C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p])
+_attn_core_bwd = L._sig('vdx_attention_core_backward_ex', C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p])
 _sla_scr = L._sig('vdx_sla_backward_scratch_floats', C.c_size_t, [C.c_int, C.c_int])
 _sla_core_bwd = L._sig('vdx_sla_core_backward', C.c_int, [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_void_p])
 
 
-def attention_core_backward(qkv, d_o, B, Fr, H, W, heads, temporal):
+def attention_core_backward(qkv, d_o, B, Fr, H, W, heads, temporal, bf16_operands=False):
     outs = [torch.empty_like(d_o) for _ in range(4)]
-    L.check(_attn_core_bwd(L.ptr(qkv), L.ptr(d_o), *[L.ptr(t) for t in outs], B, Fr, H, W, heads, int(temporal), L.stream_ptr()))
+    L.check(_attn_core_bwd(L.ptr(qkv), L.ptr(d_o), *[L.ptr(t) for t in outs], B, Fr, H, W, heads, int(temporal), int(bool(bf16_operands)),
+                           L.stream_ptr()))
     return outs      # o, dq, dk, dv
 
 
