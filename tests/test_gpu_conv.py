@@ -105,3 +105,40 @@ def test_conv_concat_and_prologue(mode):
         ref2 = R.conv_1kk(h, k2, None)
         tol = 2e-5 if mode == 'f32' else 3e-3     # bf16: rounding boundary flips of the fused activation
         assert _rel(y2.cpu().double(), ref2) < tol, (mode, use_ss, _rel(y2.cpu().double(), ref2))
+
+
+@pytest.mark.parametrize('act_bf16', [False, True])
+def test_persistent_c64_conv(act_bf16):
+    """The persistent level-0 specialisation (conv64p_kernel: 3x3, 64 -> 64 channels, bf16 mode, >= 1024 tiles of 16x16 pixels,
+    weights resident in LDS): plain form with statistics, then the fused-prologue form consuming it, two samples so that the
+    per-sample flush of the register-resident statistics and the coefficient switch are exercised; fp32 and bf16 tensors."""
+    from video_diffusion_nnx_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(11)
+    B, Fr, H, W, C = 2, 32, 64, 64, 64                     # 64 frames x 16 tiles = 1024 tiles
+    x = torch.randn(B, Fr, H, W, C, generator=g)
+    x[1] *= 1.7                                            # different statistics per sample
+    kern = torch.randn(1, 3, 3, C, C, generator=g) / (9 * C) ** 0.5
+    bias = torch.randn(C, generator=g)
+    pw = ops.pack_conv_weights(kern.to(dev), 'bf16')
+    stats1 = ops.gn_stats_zeros(B, 8, dev)
+    xin = x.to(dev).to(torch.bfloat16) if act_bf16 else x.to(dev)
+    y1 = ops.conv_forward(xin, pw, C, mode='bf16', bias=bias.to(dev), out_stats=stats1, y_bf16=act_bf16)
+    torch.cuda.synchronize()
+    ref1 = R.conv_1kk(_bf16r(x).double(), _bf16r(kern).double(), bias.double())
+    y1f = y1.float().cpu().double()
+    assert _rel(y1f, ref1) < (4e-3 if act_bf16 else 2e-6)    # bf16 output: one rounding of the result
+    s = ops.gn_stats_reduce(stats1, B, 8).cpu()
+    yg = ref1.reshape(B, -1, 8, C // 8)
+    np.testing.assert_allclose(s[..., 0], yg.sum(dim=(1, 3)), rtol=2e-3, atol=5.0)       # statistics are taken before the output rounding
+    np.testing.assert_allclose(s[..., 1], (yg * yg).sum(dim=(1, 3)), rtol=2e-3)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    ss = torch.randn(B, 2 * C, generator=g) * 0.3
+    kern2 = torch.randn(1, 3, 3, C, C, generator=g) / (9 * C) ** 0.5
+    pw2 = ops.pack_conv_weights(kern2.to(dev), 'bf16')
+    y2 = ops.conv_forward(y1, pw2, C, mode='bf16', in_stats=stats1, gamma=gamma.to(dev), beta=beta.to(dev), scale_shift=ss.to(dev),
+                          y_bf16=act_bf16)
+    h = R.group_norm(y1f, gamma.double(), beta.double(), 8)
+    h = R.silu(h * (ss[:, None, None, None, :C].double() + 1) + ss[:, None, None, None, C:].double())
+    ref2 = R.conv_1kk(_bf16r(h.float()).double(), _bf16r(kern2).double(), None)
+    assert _rel(y2.float().cpu().double(), ref2) < 5e-3

@@ -340,6 +340,244 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
     }
 }
 
+// ---- persistent specialisation: 3x3 / stride 1, Cin = Cout = 64, bf16 mode (the 8 level-0 convs of the N shape) -----------
+// One 512-thread workgroup per CU walks a contiguous range of 16x16-pixel tiles.  The whole weight set (9 taps x 64 x 64 bf16
+// = 72 KB) is loaded into LDS once and stays there: no per-tap weight staging and no barrier inside the 144-MFMA tap loop.
+// The halo tile is double buffered: the next tile's global loads are issued before the MFMAs of the current one and written
+// (with the GroupNorm/SiLU prologue applied) after its epilogue; one barrier per tile.  GroupNorm partial sums of the output stay
+// in registers across tiles and are flushed when the sample changes.  LDS rows are 128 bytes, unpadded, with the 16-byte chunk
+// index XOR-ed by (row & 7): conflict-free for the ds_read_b128 lane groups of 16 consecutive rows (MI355X_MICROARCH.md, LDS).
+constexpr int C64_HALO = 18 * 18;
+__device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + 16 * (chunk ^ (row & 7)); }
+
+template <bool IN16>
+__global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
+    using M = Mma<MODE_BF16>;
+    constexpr int PCH = IN16 ? 8 : 4;                 // channels per 16-byte global piece
+    constexpr int PPR = 64 / PCH;                     // pieces per pixel
+    constexpr int NPIECE = C64_HALO * PPR;
+    constexpr int NU = (NPIECE + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Wl = smem;                                  // [9 * 64 rows][128 B]
+    char* Al = Wl + 9 * 64 * 128;                     // [2][324 rows][128 B]
+    float* coefA = reinterpret_cast<float*>(Al + 2 * C64_HALO * 128);
+    float* coefD = coefA + 64;
+    float* gmean = coefD + 64;                        // [32][mean, rstd]
+    float* chs = gmean + 64;                          // [2][64] channel sum / sumsq of the current sample
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    const int tiles_x = P.W >> 4, tiles_pf = tiles_x * (P.H >> 4);
+    const int t0 = blockIdx.x * tiles_per_block, t1 = min(t0 + tiles_per_block, total_tiles);
+    if (t0 >= t1) return;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x0), 0, P.x0_bytes, 0x00020000);
+    for (int i = tid; i < 9 * 64 * 8; i += 512) {     // packed [tap][co][64 ci] bf16: 128-byte rows already
+        const int row = i >> 3, c = i & 7;
+        *reinterpret_cast<uint4*>(Wl + swz(row, c)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) + (size_t)row * 128 + c * 16);
+    }
+    if (tid < 128) chs[tid] = 0.f;
+
+    // per-thread staging pieces (constant over tiles): halo position, channel piece, LDS byte offset
+    int piy[NU], pix_[NU], ploff[NU], pch[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i = tid + 512 * u;
+        const int hp = min(i / PPR, C64_HALO - 1), pc = i % PPR;
+        piy[u] = (i < NPIECE) ? hp / 18 : -100;       // -100: never in range
+        pix_[u] = hp % 18;
+        pch[u] = pc * PCH;
+        ploff[u] = IN16 ? swz(hp, pc) : (swz(hp, pc >> 1) + 8 * (pc & 1));
+    }
+    auto decode = [&](int t, int& f, int& ty, int& tx) { f = t / tiles_pf; const int r = t - f * tiles_pf; ty = r / tiles_x; tx = r - ty * tiles_x; };
+
+    u32x4 sreg[NU];
+    unsigned okmask = 0;
+    auto stage_load = [&](int t) {
+        int f, ty, tx; decode(t, f, ty, tx);
+        okmask = 0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int gy = ty * 16 - 1 + piy[u], gx = tx * 16 - 1 + pix_[u];
+            const bool ok = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+            okmask |= ok ? (1u << u) : 0u;
+            const unsigned off = ok ? (unsigned)(((f * P.H + gy) * P.W + gx) * 64 + pch[u]) * (IN16 ? 2u : 4u) : OOB;
+            sreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
+        }
+    };
+    auto stage_store = [&](int buf) {
+        char* dst = Al + buf * (C64_HALO * 128);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if (piy[u] < 0) continue;
+            const bool ok = (okmask >> u) & 1u;
+            if (IN16) {
+                u32x4 v = sreg[u];
+                if (P.pro) {
+                    const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+                    unsigned o4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float2 a = *reinterpret_cast<const float2*>(coefA + pch[u] + 2 * k);
+                        const float2 d = *reinterpret_cast<const float2*>(coefD + pch[u] + 2 * k);
+                        const float lo = silu_f(fmaf(__uint_as_float(w4[k] << 16), a.x, d.x));
+                        const float hi = silu_f(fmaf(__uint_as_float(w4[k] & 0xFFFF0000u), a.y, d.y));
+                        o4[k] = ok ? pack_bf16x2(lo, hi) : 0u;        // zero padding stays zero AFTER the activation
+                    }
+                    v = u32x4{o4[0], o4[1], o4[2], o4[3]};
+                }
+                *reinterpret_cast<u32x4*>(dst + ploff[u]) = v;
+            } else {
+                float4 f = make_float4(__uint_as_float(sreg[u].x), __uint_as_float(sreg[u].y), __uint_as_float(sreg[u].z), __uint_as_float(sreg[u].w));
+                if (P.pro) {
+                    const float4 a = *reinterpret_cast<const float4*>(coefA + pch[u]);
+                    const float4 d = *reinterpret_cast<const float4*>(coefD + pch[u]);
+                    f.x = ok ? silu_f(fmaf(f.x, a.x, d.x)) : 0.f; f.y = ok ? silu_f(fmaf(f.y, a.y, d.y)) : 0.f;
+                    f.z = ok ? silu_f(fmaf(f.z, a.z, d.z)) : 0.f; f.w = ok ? silu_f(fmaf(f.w, a.w, d.w)) : 0.f;
+                }
+                *reinterpret_cast<uint2*>(dst + ploff[u]) = make_uint2(pack_bf16x2(f.x, f.y), pack_bf16x2(f.z, f.w));
+            }
+        }
+    };
+    // GroupNorm-apply coefficients of sample b (all threads call; ends with a barrier)
+    auto make_coef = [&](int b) {
+        if (!P.pro) return;
+        if (tid < P.groups) {
+            float m, rsd;
+            gn_mean_rstd(P.in_stats, b, tid, P.groups, (double)P.F * P.H * P.W * (64 / P.groups), m, rsd);
+            gmean[2 * tid] = m; gmean[2 * tid + 1] = rsd;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int g = tid / (64 / P.groups);
+            const float m = gmean[2 * g], rsd = gmean[2 * g + 1];
+            float sc = 1.f, sh = 0.f;
+            if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + tid] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + 64 + tid]; }
+            coefA[tid] = rsd * P.gamma[tid] * sc;
+            coefD[tid] = (P.beta[tid] - m * rsd * P.gamma[tid]) * sc + sh;
+        }
+        __syncthreads();
+    };
+    // flush the register partial sums of sample b into out_stats (all threads call)
+    f32x4 ssum[4], ssq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ssum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    auto flush_stats = [&](int b) {
+        if (!P.out_stats) return;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s1 = reduce16(ssum[tm][e]), s2 = reduce16(ssq[tm][e]);
+                if (lp == 0) { atomicAdd(&chs[tm * 16 + 4 * q + e], s1); atomicAdd(&chs[64 + tm * 16 + 4 * q + e], s2); }
+                ssum[tm][e] = 0.f; ssq[tm][e] = 0.f;
+            }
+        __syncthreads();
+        const int cpg = 64 / P.out_groups;
+        if (tid < 2 * P.out_groups) {
+            const int g = tid >> 1, which = tid & 1;
+            float t = 0.f;
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) t += chs[which * 64 + c];
+            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * P.out_groups + g) * 2 + which, (double)t);
+        }
+        __syncthreads();
+        if (tid < 128) chs[tid] = 0.f;
+        __syncthreads();
+    };
+
+    // fragment addressing: wave owns output rows py = 2 * wave + tn of the tile, pixel px = lp
+    int hpb[2];
+    hpb[0] = (2 * wave) * 18 + lp; hpb[1] = hpb[0] + 18;
+    float4 bias4[4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) bias4[tm] = P.bias ? *reinterpret_cast<const float4*>(P.bias + tm * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int fcur, tyc, txc;
+    decode(t0, fcur, tyc, txc);
+    int bcur = fcur / P.F;
+    __syncthreads();                                  // weights + chs visible
+    make_coef(bcur);
+    stage_load(t0);
+    stage_store(0);
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        const bool more = t + 1 < t1;
+        if (more) stage_load(t + 1);
+        // ---- 9 taps x 2 chunks x (4 x 2) MFMAs, no barrier ----
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const char* At = Al + buf * (C64_HALO * 128);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            int boff[2];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) { const int hp = hpb[tn] + dy * 18 + dx; boff[tn] = swz(hp, q); }
+            const int woff = swz(tap * 64 + lp, q);
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                uint4 af[4], bf[2];
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) af[tm] = *reinterpret_cast<const uint4*>(Wl + ((woff + tm * 16 * 128) ^ (ch * 64)));
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(At + (boff[tn] ^ (ch * 64)));
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
+            }
+        }
+        // ---- epilogue of tile t ----
+        {
+            const int oy0 = tyc * 16 + 2 * wave, ox = txc * 16 + lp;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const size_t gout = ((size_t)(fcur * P.H + oy0 + tn) * P.W + ox) * 64;
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+                    const float4 v = make_float4(acc[tm][tn][0] + bias4[tm].x, acc[tm][tn][1] + bias4[tm].y, acc[tm][tn][2] + bias4[tm].z, acc[tm][tn][3] + bias4[tm].w);
+                    store4_f32_or_bf16(P.y, gout + tm * 16 + 4 * q, v, P.y_bf16);
+                    ssum[tm][0] += v.x; ssum[tm][1] += v.y; ssum[tm][2] += v.z; ssum[tm][3] += v.w;
+                    ssq[tm][0] += v.x * v.x; ssq[tm][1] += v.y * v.y; ssq[tm][2] += v.z * v.z; ssq[tm][3] += v.w * v.w;
+                }
+            }
+        }
+        if (more) {
+            int fn, tyn, txn;
+            decode(t + 1, fn, tyn, txn);
+            const int bn = fn / P.F;
+            if (bn != bcur) {                         // uniform: the next tile belongs to another sample
+                flush_stats(bcur);
+                make_coef(bn);
+                bcur = bn;
+            }
+            stage_store(buf ^ 1);
+            fcur = fn; tyc = tyn; txc = txn;
+        }
+        __syncthreads();
+    }
+    flush_stats(bcur);
+}
+
+static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
+    const int total = a.NF * (a.H >> 4) * (a.W >> 4);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const int grid = std::min(total, cus);
+    const int tpb = (total + grid - 1) / grid;
+    const int nblocks = (total + tpb - 1) / tpb;
+    const size_t lds = 9 * 64 * 128 + 2 * (size_t)C64_HALO * 128 + (64 + 64 + 64 + 128) * 4;
+    auto launch = [&](auto kfn) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(512), lds, st, a, tpb, total);
+        return hipGetLastError();
+    };
+    return a.x0_bf16 ? launch(conv64p_kernel<true>) : launch(conv64p_kernel<false>);
+}
+
 // Flax kernel [taps][Cin][Cout] fp32  ->  packed [taps][Cout][CinPad] in the MMA element type, zero padded.
 template <int MODE>
 __global__ void pack_weights_kernel(const float* __restrict__ src, void* __restrict__ dst, int taps, int Cin, int Cout, int CinPad) {
@@ -432,6 +670,14 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     const size_t b0 = npix * a.C0 * (a.x0_bf16 ? 2 : 4), b1 = npix * a.C1 * (a.x1_bf16 ? 2 : 4), bw = (size_t)(a.kind ? 16 : a.kh * a.kw) * a.wrows * a.CinPad * ES;
     if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
     a.x0_bytes = (unsigned)b0; a.x1_bytes = (unsigned)b1; a.w_bytes = (unsigned)bw;
+    {   // persistent specialisation for the level-0 shape (see conv64p_kernel); VDX_CONV64P=0 disables it
+        static const int use64p = getenv("VDX_CONV64P") ? atoi(getenv("VDX_CONV64P")) : 1;
+        const long tiles = (long)a.NF * (a.H / 16) * (a.W / 16);
+        if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.C0 == 64 && a.C1 == 0 && a.Cout == 64 &&
+            a.wrows == 64 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
+            (!a.out_stats || (a.out_groups <= 32 && 64 % a.out_groups == 0)))
+            return launch_conv64p(a, st);
+    }
     // variant: 64-channel tiles take 256 pixels per workgroup (stride 1) so every wave owns a 64x64 tile
     const int BC = a.Cout <= 64 ? 64 : 128;
     // 8-wave workgroups (each wave 32 pixels x 64 channels of the same workgroup tile): 4 waves per SIMD instead of 2;
