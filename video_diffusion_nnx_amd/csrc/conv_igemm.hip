@@ -500,17 +500,26 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     stage_load(t0);
     stage_store(0);
     __syncthreads();
+    int bcoef = bcur;                                 // sample the prologue coefficients in LDS belong to
     for (int t = t0; t < t1; ++t) {
         const int buf = (t - t0) & 1;
         const bool more = t + 1 < t1;
-        if (more) stage_load(t + 1);
-        // ---- 9 taps x 2 chunks x (4 x 2) MFMAs, no barrier ----
+        int fn = fcur, tyn = tyc, txn = txc, bn = bcur;
+        if (more) {
+            stage_load(t + 1);
+            decode(t + 1, fn, tyn, txn);
+            bn = fn / P.F;
+            if (bn != bcoef) { make_coef(bn); bcoef = bn; }          // uniform; nobody reads the coefficients during the MFMAs
+        }
+        // ---- 9 taps x 2 chunks x (4 x 2) MFMAs, no barrier; the next tile is written to the other buffer half way through,
+        //      so its prologue arithmetic and LDS writes sit between MFMAs instead of after them ----
         f32x4 acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         const char* At = Al + buf * (C64_HALO * 128);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
+            if (tap == 5 && more) stage_store(buf ^ 1);
             const int dy = tap / 3, dx = tap % 3;
             int boff[2];
 #pragma unroll
@@ -544,18 +553,8 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
                 }
             }
         }
-        if (more) {
-            int fn, tyn, txn;
-            decode(t + 1, fn, tyn, txn);
-            const int bn = fn / P.F;
-            if (bn != bcur) {                         // uniform: the next tile belongs to another sample
-                flush_stats(bcur);
-                make_coef(bn);
-                bcur = bn;
-            }
-            stage_store(buf ^ 1);
-            fcur = fn; tyc = tyn; txc = txn;
-        }
+        if (more && bn != bcur) { flush_stats(bcur); bcur = bn; }    // uniform: the next tile belongs to another sample
+        fcur = fn; tyc = tyn; txc = txn;
         __syncthreads();
     }
     flush_stats(bcur);
