@@ -17,6 +17,7 @@
 // a 2-deep register->LDS ring.  Accumulators: lane (r,q) holds channels 4q..4q+3 of pixel r (vdx_common.h).
 #include "vdx_common.h"
 #include "vdx_internal.h"
+#include "model.h"
 #include <stdlib.h>
 
 namespace vdx {
@@ -609,6 +610,29 @@ __global__ void pack_weights_t_kernel(const float* __restrict__ src, void* __res
     }
 }
 
+// every tensor of a parameter (re)packing in one launch: blockIdx.y = job (model.h PackJob), grid-stride over its elements
+template <int MODE>
+__global__ void pack_jobs_kernel(const float* __restrict__ params, char* __restrict__ dst_base, const PackJob* __restrict__ jobs) {
+    const PackJob J = jobs[blockIdx.y];
+    const float* src = params + J.src;
+    char* dstc = dst_base + J.dst;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < J.n; i += (long)gridDim.x * blockDim.x) {
+        if (J.kind == 2) { reinterpret_cast<float*>(dstc)[i] = src[i]; continue; }
+        const int k = (int)(i % J.Pad);
+        const long r = i / J.Pad;
+        float v;
+        if (J.kind == 0) {                                    // row = output channel, k = input channel
+            const int co = (int)(r % J.Cout), t = (int)(r / J.Cout);
+            v = (k < J.Cin) ? src[((size_t)t * J.Cin + k) * J.Cout + co] : 0.f;
+        } else {                                              // row = input channel, k = output channel, taps reversed
+            const int ci = (int)(r % J.Cin), t = (int)(r / J.Cin);
+            v = (k < J.Cout) ? src[((size_t)(J.taps - 1 - t) * J.Cin + ci) * J.Cout + k] : 0.f;
+        }
+        if (MODE == MODE_F32) reinterpret_cast<float*>(dstc)[i] = v;
+        else reinterpret_cast<__bf16*>(dstc)[i] = (__bf16)v;
+    }
+}
+
 // ---- host-side launchers ----------------------------------------------------------------------------
 
 static void choose_patch(int BM, int NF, int F, int Ho, int Wo, int stride, int K, int& PH, int& PW, int& NP) {
@@ -645,6 +669,14 @@ hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, 
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
     if (mode == MODE_F32) hipLaunchKernelGGL(pack_weights_kernel<MODE_F32>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CinPad);
     else hipLaunchKernelGGL(pack_weights_kernel<MODE_BF16>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CinPad);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_jobs(int mode, const float* params, void* dst_base, const PackJob* d_jobs, int njobs, hipStream_t st) {
+    if (njobs <= 0) return hipSuccess;
+    dim3 grid(48, njobs);
+    if (mode == MODE_F32) hipLaunchKernelGGL(pack_jobs_kernel<MODE_F32>, grid, dim3(256), 0, st, params, reinterpret_cast<char*>(dst_base), d_jobs);
+    else hipLaunchKernelGGL(pack_jobs_kernel<MODE_BF16>, grid, dim3(256), 0, st, params, reinterpret_cast<char*>(dst_base), d_jobs);
     return hipGetLastError();
 }
 

@@ -9,6 +9,10 @@ namespace vdx {
 struct ParamInfo { std::string name; int ndim; long shape[6]; long offset; long numel; };
 struct Slot { std::string name; long floats_per_sample; long offset_per_sample; };
 
+// one tensor of vdx_pack_params / vdx_pack_params_bwd: kind 0 = [taps][Cin][Cout] -> [taps][Cout][Pad] (MFMA element type),
+// 1 = transposed + tap-reversed [taps][Cin (rows)][Pad], 2 = plain fp32 copy of n floats; src in floats, dst in bytes
+struct PackJob { long src, dst, n; int taps, Cin, Cout, Pad, kind, pad_; };
+
 struct ResP {
     std::string name;
     int cin = 0, cout = 0; bool has_mlp = false, has_res = false; int ss_index = -1;
@@ -33,6 +37,7 @@ struct Model {
     size_t packed_t_bytes = 0;
     std::vector<Slot> slots; long act_floats_per_sample = 0;
     std::vector<SsLayer> ss_layers; long ss_floats_per_sample = 0; SsLayer* d_ss_layers = nullptr;
+    std::vector<PackJob> pack_jobs, pack_t_jobs; PackJob* d_pack_jobs = nullptr; PackJob* d_pack_t_jobs = nullptr;   // device copies owned by the handle
     int n_stats = 0;
     size_t sla_ws_bytes_per_sample = 0;
     long rel_pos_emb, init_w, init_b, t_w1, t_b1, t_w2, t_b2, null_cond, fin_w, fin_b;
@@ -43,6 +48,7 @@ struct Model {
 };
 
 int model_build(Model* m);
+void model_build_pack_tables(Model* m);        // fills pack_jobs / pack_t_jobs (host); the handle uploads them
 size_t model_workspace_bytes(const Model* m, int B);
 hipError_t model_pack(const Model* m, const float* params, void* packed, hipStream_t st);
 size_t model_bwd_workspace_bytes(const Model* m, int B);

@@ -270,59 +270,53 @@ size_t model_workspace_bytes(const Model* m, int B) {
 
 // ---- packing ------------------------------------------------------------------------------------------------
 
-static hipError_t pack_res(const Model* m, const ResP& r, const float* p, char* pk, hipStream_t st) {
-    hipError_t e = launch_pack_weights(m->mode, p + r.b1_w, pk + r.pk_b1, 9, r.cin, r.cout, st);
-    if (e != hipSuccess) return e;
-    e = launch_pack_weights(m->mode, p + r.b2_w, pk + r.pk_b2, 9, r.cout, r.cout, st);
-    if (e != hipSuccess) return e;
-    if (r.has_res) e = launch_pack_weights(m->mode, p + r.rc_w, pk + r.pk_rc, 1, r.cin, r.cout, st);
-    return e;
-}
-
-static hipError_t pack_attn(const Model* m, const AttnP& a, const float* p, char* pk, hipStream_t st) {
-    const int HD = m->cfg.attn_heads * m->cfg.attn_dim_head;
-    const size_t one = conv_packed_bytes(m->mode, 1, a.C, HD);
-    for (int i = 0; i < 3; ++i) {
-        hipError_t e = launch_pack_weights(m->mode, p + a.w[i], pk + a.pk_qkv + i * one, 1, a.C, HD, st);
-        if (e != hipSuccess) return e;
-        e = hipMemcpyAsync(pk + a.pk_bqkv + (size_t)i * HD * 4, p + a.b[i], (size_t)HD * 4, hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return e;
-    }
-    return launch_pack_weights(m->mode, p + a.o_w, pk + a.pk_o, 1, HD, a.C, st);
-}
-
-static hipError_t pack_sla(const Model* m, const SlaP& s, const float* p, char* pk, hipStream_t st) {
+void model_build_pack_tables(Model* m) {
     const int HD = m->cfg.attn_heads * 32;
-    for (int i = 0; i < 3; ++i) {
-        hipError_t e = launch_pack_weights(m->mode, p + s.w[i], pk + s.pk[i], 1, s.C, HD, st);
-        if (e != hipSuccess) return e;
+    auto pad = [&](int k) { return conv_cin_pad(m->mode, k); };
+    auto fwd = [&](long src, size_t dst, int taps, int cin, int cout) {
+        PackJob j{}; j.src = src; j.dst = (long)dst; j.taps = taps; j.Cin = cin; j.Cout = cout; j.Pad = pad(cin); j.kind = 0;
+        j.n = (long)taps * cout * j.Pad; m->pack_jobs.push_back(j);
+    };
+    auto cpy = [&](long src, size_t dst, long n) { PackJob j{}; j.src = src; j.dst = (long)dst; j.n = n; j.kind = 2; j.Pad = 1; m->pack_jobs.push_back(j); };
+    auto bwd = [&](long src, size_t dst, int taps, int cin, int cout) {
+        PackJob j{}; j.src = src; j.dst = (long)dst; j.taps = taps; j.Cin = cin; j.Cout = cout; j.Pad = pad(cout); j.kind = 1;
+        j.n = (long)taps * cin * j.Pad; m->pack_t_jobs.push_back(j);
+    };
+    auto res = [&](const ResP& r) {
+        fwd(r.b1_w, r.pk_b1, 9, r.cin, r.cout); fwd(r.b2_w, r.pk_b2, 9, r.cout, r.cout);
+        bwd(r.b1_w, r.pt_b1, 9, r.cin, r.cout); bwd(r.b2_w, r.pt_b2, 9, r.cout, r.cout);
+        if (r.has_res) { fwd(r.rc_w, r.pk_rc, 1, r.cin, r.cout); bwd(r.rc_w, r.pt_rc, 1, r.cin, r.cout); }
+    };
+    auto attn = [&](const AttnP& a) {
+        const size_t one = conv_packed_bytes(m->mode, 1, a.C, HD);
+        for (int i = 0; i < 3; ++i) {
+            fwd(a.w[i], a.pk_qkv + i * one, 1, a.C, HD);
+            cpy(a.b[i], a.pk_bqkv + (size_t)i * HD * 4, HD);
+            bwd(a.w[i], a.pt_w[i], 1, a.C, HD);
+        }
+        fwd(a.o_w, a.pk_o, 1, HD, a.C); bwd(a.o_w, a.pt_o, 1, HD, a.C);
+    };
+    auto sla = [&](const SlaP& s) {
+        for (int i = 0; i < 3; ++i) { fwd(s.w[i], s.pk[i], 1, s.C, HD); bwd(s.w[i], s.pt_w[i], 1, s.C, HD); }
+        fwd(s.o_w, s.pk_o, 1, HD, s.C); bwd(s.o_w, s.pt_o, 1, HD, s.C);
+    };
+    m->pack_jobs.clear(); m->pack_t_jobs.clear();
+    attn(m->init_attn);
+    for (int pass = 0; pass < 2; ++pass) {
+        const std::vector<Level>& lv = pass ? m->ups : m->downs;
+        for (const Level& L : lv) {
+            res(L.res0); res(L.res1);
+            if (L.has_sla) sla(L.sla);
+            attn(L.attn);
+            if (L.has_resample) { fwd(L.rs_w, L.pk_rs, 16, L.cout, L.cout); bwd(L.rs_w, L.pt_rs, 16, L.cout, L.cout); }
+        }
     }
-    return launch_pack_weights(m->mode, p + s.o_w, pk + s.pk_o, 1, HD, s.C, st);
+    res(m->mid1); attn(m->mid_sattn); attn(m->mid_tattn); res(m->mid2); res(m->fin);
 }
 
 hipError_t model_pack(const Model* m, const float* p, void* packed, hipStream_t st) {
-    char* pk = reinterpret_cast<char*>(packed);
-    hipError_t e;
-#define VDX_E(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-    VDX_E(pack_attn(m, m->init_attn, p, pk, st));
-    for (int pass = 0; pass < 2; ++pass) {
-        const std::vector<Level>& lv = pass ? m->ups : m->downs;
-        for (size_t i = 0; i < lv.size(); ++i) {
-            const Level& L = lv[i];
-            VDX_E(pack_res(m, L.res0, p, pk, st));
-            VDX_E(pack_res(m, L.res1, p, pk, st));
-            if (L.has_sla) VDX_E(pack_sla(m, L.sla, p, pk, st));
-            VDX_E(pack_attn(m, L.attn, p, pk, st));
-            if (L.has_resample) VDX_E(launch_pack_weights(m->mode, p + L.rs_w, pk + L.pk_rs, 16, L.cout, L.cout, st));
-        }
-    }
-    VDX_E(pack_res(m, m->mid1, p, pk, st));
-    VDX_E(pack_attn(m, m->mid_sattn, p, pk, st));
-    VDX_E(pack_attn(m, m->mid_tattn, p, pk, st));
-    VDX_E(pack_res(m, m->mid2, p, pk, st));
-    VDX_E(pack_res(m, m->fin, p, pk, st));
-#undef VDX_E
-    return hipSuccess;
+    if (!m->d_pack_jobs) return hipErrorInvalidValue;
+    return launch_pack_jobs(m->mode, p, packed, m->d_pack_jobs, (int)m->pack_jobs.size(), st);
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------

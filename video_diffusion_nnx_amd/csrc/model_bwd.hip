@@ -196,39 +196,8 @@ size_t model_bwd_workspace_bytes(const Model* m, int B) {
 }
 
 hipError_t model_pack_t(const Model* m, const float* p, void* packed_t, hipStream_t st) {
-    char* pt = reinterpret_cast<char*>(packed_t);
-    hipError_t e;
-    const int HD = m->cfg.attn_heads * 32;
-#define VDX_E(x) do { e = (x); if (e != hipSuccess) return e; } while (0)
-    auto res = [&](const ResP& r) -> hipError_t {
-        VDX_E(launch_pack_weights_t(m->mode, p + r.b1_w, pt + r.pt_b1, 9, r.cin, r.cout, st));
-        VDX_E(launch_pack_weights_t(m->mode, p + r.b2_w, pt + r.pt_b2, 9, r.cout, r.cout, st));
-        if (r.has_res) VDX_E(launch_pack_weights_t(m->mode, p + r.rc_w, pt + r.pt_rc, 1, r.cin, r.cout, st));
-        return hipSuccess;
-    };
-    auto attn = [&](const AttnP& a) -> hipError_t {
-        for (int i = 0; i < 3; ++i) VDX_E(launch_pack_weights_t(m->mode, p + a.w[i], pt + a.pt_w[i], 1, a.C, HD, st));
-        VDX_E(launch_pack_weights_t(m->mode, p + a.o_w, pt + a.pt_o, 1, HD, a.C, st));
-        return hipSuccess;
-    };
-    auto sla = [&](const SlaP& s) -> hipError_t {
-        for (int i = 0; i < 3; ++i) VDX_E(launch_pack_weights_t(m->mode, p + s.w[i], pt + s.pt_w[i], 1, s.C, HD, st));
-        VDX_E(launch_pack_weights_t(m->mode, p + s.o_w, pt + s.pt_o, 1, HD, s.C, st));
-        return hipSuccess;
-    };
-    VDX_E(attn(m->init_attn));
-    for (int pass = 0; pass < 2; ++pass) {
-        const std::vector<Level>& lv = pass ? m->ups : m->downs;
-        for (const Level& L : lv) {
-            VDX_E(res(L.res0)); VDX_E(res(L.res1));
-            if (L.has_sla) VDX_E(sla(L.sla));
-            VDX_E(attn(L.attn));
-            if (L.has_resample) VDX_E(launch_pack_weights_t(m->mode, p + L.rs_w, pt + L.pt_rs, 16, L.cout, L.cout, st));
-        }
-    }
-    VDX_E(res(m->mid1)); VDX_E(attn(m->mid_sattn)); VDX_E(attn(m->mid_tattn)); VDX_E(res(m->mid2)); VDX_E(res(m->fin));
-#undef VDX_E
-    return hipSuccess;
+    if (!m->d_pack_t_jobs) return hipErrorInvalidValue;
+    return launch_pack_jobs(m->mode, p, packed_t, m->d_pack_t_jobs, (int)m->pack_t_jobs.size(), st);
 }
 
 int model_backward(const Model* m, BwdState* state, const float* params, const void* packed, const void* packed_t, const float* x,

@@ -171,6 +171,14 @@ int vdx_create(const vdx_config* cfg, vdx_handle** out) {
             hipError_t e = hipMalloc(reinterpret_cast<void**>(&h->model.d_ss_layers), tb);
             if (e == hipSuccess) e = hipMemcpy(h->model.d_ss_layers, h->model.ss_layers.data(), tb, hipMemcpyHostToDevice);
             if (e != hipSuccess) { delete h; return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); }
+            vdx::model_build_pack_tables(&h->model);
+            for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+                const std::vector<vdx::PackJob>& v = k ? h->model.pack_t_jobs : h->model.pack_jobs;
+                vdx::PackJob** d = k ? &h->model.d_pack_t_jobs : &h->model.d_pack_jobs;
+                e = hipMalloc(reinterpret_cast<void**>(d), v.size() * sizeof(vdx::PackJob));
+                if (e == hipSuccess) e = hipMemcpy(*d, v.data(), v.size() * sizeof(vdx::PackJob), hipMemcpyHostToDevice);
+            }
+            if (e != hipSuccess) { vdx_destroy(h); return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); }
         }   // without a device the handle still serves the layout queries (CPU-side tests)
     }
     *out = h;
@@ -182,6 +190,8 @@ void vdx_destroy(vdx_handle* h) {
     if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     if (h->model.d_ss_layers) (void)hipFree(h->model.d_ss_layers);
+    if (h->model.d_pack_jobs) (void)hipFree(h->model.d_pack_jobs);
+    if (h->model.d_pack_t_jobs) (void)hipFree(h->model.d_pack_t_jobs);
     delete h;
 }
 

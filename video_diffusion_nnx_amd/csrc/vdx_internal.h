@@ -133,6 +133,8 @@ struct WgradArgs {
     int taps, sa, sb, ext, halo, Hm, Wm, Hy, Wy, PH, PW, co_tiles;
 };
 hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st);
+struct PackJob;
+hipError_t launch_pack_jobs(int mode, const float* params, void* dst_base, const PackJob* d_jobs, int njobs, hipStream_t st);
 hipError_t launch_colsum(const float* x, float* out, long rows, int C, hipStream_t st);
 hipError_t launch_add_inplace(float* y, const float* x, long n, hipStream_t st);
 
