@@ -131,6 +131,7 @@ struct WgradArgs {
     int bf16_mma;                                          // bf16 MFMA operands (bf16 mode) instead of exact f32
     // completed by the launcher
     int taps, sa, sb, ext, halo, Hm, Wm, Hy, Wy, PH, PW, co_tiles;
+    unsigned m_iw, m_bw;                                   // magic multipliers (div_magic) of the staged window widths
 };
 hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st);
 struct PackJob;

@@ -183,12 +183,17 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* row0, const char* row1) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int NT>
-__global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradArgs P) {
+// NT taps per workgroup, split over NG groups of 4 waves (NTW = taps per wave): fewer live accumulators, and NG x 256 threads
+// share the staging of the same patch.
+template <int NT, int NG>
+__global__ __launch_bounds__(256 * NG) void conv_wgrad16_kernel(const WgradArgs P) {
+    constexpr int NTH = 256 * NG;
+    constexpr int NTW = (NT + NG - 1) / NG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = (tid >> 6) & 3, wg = tid >> 8;
     const int r = lane & 15, q = lane >> 4;
     const int wi = w & 1, wo = w >> 1;
+    const int tw0 = wg * NTW;                                // first tap (within the workgroup's NT) of this wave
     const int ci0 = blockIdx.y * 64, co0 = (blockIdx.z % P.co_tiles) * 64;
     const int tap0 = (blockIdx.z / P.co_tiles) * NT;
     const int Cin = P.C0 + P.C1;
@@ -215,9 +220,9 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradArgs P) {
     }
     if (tid < 64) bsum[tid] = 0.f;
 
-    f32x4 acc[NT][2][2];
+    f32x4 acc[NTW][2][2];
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int i = 0; i < 2; ++i) { acc[t][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
@@ -261,9 +266,9 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradArgs P) {
             last_b = b;
             __syncthreads();
         }
-        for (int i = tid; i < HPX * 16; i += 256) {
+        for (int i = tid; i < HPX * 16; i += NTH) {
             const int hp = i >> 4, pc = i & 15;
-            const int iy = hp / IW, ix = hp - iy * IW;
+            const int iy = div_magic(hp, P.m_iw), ix = hp - iy * IW;
             const int gy = iy0 + iy, gx = ix0 + ix;
             const int c = ci0 + pc * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -280,9 +285,9 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradArgs P) {
             }
             *reinterpret_cast<uint2*>(As + (size_t)hp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
         }
-        for (int i = tid; i < BPX * 16; i += 256) {
+        for (int i = tid; i < BPX * 16; i += NTH) {
             const int bp = i >> 4, pc = i & 15;
-            const int yy = bp / BW, xx = bp - yy * BW;
+            const int yy = div_magic(bp, P.m_bw), xx = bp - yy * BW;
             const int gy = my0 * P.sb + yy, gx = mx0 * P.sb + xx;
             const int c = co0 + pc * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -301,19 +306,20 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradArgs P) {
             const char* b0 = Bs + (size_t)((py0 * P.sb) * BW + px0 * P.sb) * WG_RSB + wo * 64 + pcz * 8;
             const char* b1 = Bs + (size_t)((py1 * P.sb) * BW + px1 * P.sb) * WG_RSB + wo * 64 + pcz * 8;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int tt = 0; tt < NTW; ++tt) {
+                const int t = min(tw0 + tt, NT - 1);          // a wave past the last tap repeats it (EXEC stays full); never stored
                 const bf16x8 af0 = tr_frag(a0 + tapA[t], a1 + tapA[t]);
                 const bf16x8 af1 = tr_frag(a0 + tapA[t] + 32, a1 + tapA[t] + 32);
                 const bf16x8 bf0 = tr_frag(b0 + tapB[t], b1 + tapB[t]);
                 const bf16x8 bf1 = tr_frag(b0 + tapB[t] + 32, b1 + tapB[t] + 32);
-                acc[t][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[t][0][0], 0, 0, 0);
-                acc[t][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[t][0][1], 0, 0, 0);
-                acc[t][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[t][1][0], 0, 0, 0);
-                acc[t][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc[t][1][1], 0, 0, 0);
+                acc[tt][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[tt][0][0], 0, 0, 0);
+                acc[tt][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[tt][0][1], 0, 0, 0);
+                acc[tt][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[tt][1][0], 0, 0, 0);
+                acc[tt][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc[tt][1][1], 0, 0, 0);
             }
         }
     }
-    if (do_bias) {
+    if (do_bias) {                                             // (uniform per workgroup)
         const int pc = tid & 15;
         atomicAdd(&bsum[pc * 4 + 0], bias4.x); atomicAdd(&bsum[pc * 4 + 1], bias4.y);
         atomicAdd(&bsum[pc * 4 + 2], bias4.z); atomicAdd(&bsum[pc * 4 + 3], bias4.w);
@@ -321,9 +327,9 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradArgs P) {
         if (tid < 64 && co0 + tid < P.Cout) atomicAdd(P.db + co0 + tid, bsum[tid]);
     }
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int tap = tap0 + t;
-        if (tap >= P.taps) continue;
+    for (int tt = 0; tt < NTW; ++tt) {
+        const int tap = tap0 + tw0 + tt;
+        if (tw0 + tt >= NT || tap >= P.taps) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(const WgradArgs P) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ci = ci0 + wi * 32 + i * 16 + 4 * q + e;
-                    if (ci < Cin && co < P.Cout) atomicAdd(P.dW + ((size_t)tap * Cin + ci) * P.Cout + co, acc[t][i][j][e]);
+                    if (ci < Cin && co < P.Cout) atomicAdd(P.dW + ((size_t)tap * Cin + ci) * P.Cout + co, acc[tt][i][j][e]);
                 }
             }
     }
@@ -400,10 +406,12 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
     dim3 grid((unsigned)chunks, ci_tiles, a.co_tiles * tap_groups);
     if (a.bf16_mma && a.PW == 8) {
         const size_t lds16 = ((size_t)IH * IW + (size_t)a.PH * a.sb * a.PW * a.sb) * WG_RSB + 4 * 64 * 4 + 32 * 4;
-#define VDX_WG16(NT_) do { auto kfn = conv_wgrad16_kernel<NT_>;                                                       \
+#define VDX_WG16(NT_, NG_) do { auto kfn = conv_wgrad16_kernel<NT_, NG_>;                                                \
         if (lds16 > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16); if (e != hipSuccess) return e; } \
-        hipLaunchKernelGGL(kfn, grid, dim3(256), lds16, st, a); } while (0)
-        if (NT == 1) VDX_WG16(1); else if (NT == 9) VDX_WG16(9); else VDX_WG16(8);
+        hipLaunchKernelGGL(kfn, grid, dim3(256 * NG_), lds16, st, a); } while (0)
+        a.m_iw = (unsigned)((1ull << 32) / (unsigned)IW) + 1u;
+        a.m_bw = (unsigned)((1ull << 32) / (unsigned)(a.PW * a.sb)) + 1u;
+        if (NT == 1) VDX_WG16(1, 1); else if (NT == 9) VDX_WG16(9, 2); else VDX_WG16(8, 2);
 #undef VDX_WG16
         return hipGetLastError();
     }
