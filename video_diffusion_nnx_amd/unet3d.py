@@ -354,9 +354,25 @@ class Unet3D:
         return out
 
     def forward_with_cond_scale(self, *args, cond_scale=2.0, **kwargs):
-        """reference unet3d.py:254-260."""
-        logits = self(*args, null_cond_prob=0.0, **kwargs)
+        """reference unet3d.py:254-260: eps(c), and with guidance eps(0) + s (eps(c) - eps(0)).
+
+        The two forwards of the guided case run as ONE batch of 2B (first half conditioned, second half on the null embedding,
+        selected per sample through cond_mask) -- the same arithmetic per sample, half the launches."""
         if cond_scale == 1 or not self.has_cond:
-            return logits
-        null_logits = self(*args, null_cond_prob=1.0, **kwargs)
+            return self(*args, null_cond_prob=0.0, **kwargs)
+        args = list(args)
+        x = args[0] if args else kwargs.pop('x')
+        time = args[1] if len(args) > 1 else kwargs.pop('time')
+        cond = args[2] if len(args) > 2 else kwargs.pop('cond', None)
+        assert cond is not None, 'cond must be passed in if cond_dim specified'
+        for k in ('null_cond_prob', 'cond_mask'):
+            kwargs.pop(k, None)
+        B = x.shape[0]
+        x2 = torch.cat((x, x), 0)
+        t2 = torch.cat((torch.as_tensor(time), torch.as_tensor(time)), 0)
+        c2 = torch.cat((cond, cond), 0)
+        mask = torch.zeros(2 * B, dtype=torch.bool, device=x.device)
+        mask[B:] = True                                  # second half: null conditioning
+        both = self(x2, t2, c2, cond_mask=mask, **kwargs)
+        logits, null_logits = both[:B], both[B:]
         return null_logits + (logits - null_logits) * cond_scale
