@@ -142,3 +142,32 @@ def test_persistent_c64_conv(act_bf16):
     h = R.silu(h * (ss[:, None, None, None, :C].double() + 1) + ss[:, None, None, None, C:].double())
     ref2 = R.conv_1kk(_bf16r(h.float()).double(), _bf16r(kern2).double(), None)
     assert _rel(y2.float().cpu().double(), ref2) < 5e-3
+
+
+@pytest.mark.parametrize('concat', [True, False])
+def test_persistent_c128_to_64_conv(concat):
+    """conv128x64p_kernel: 3x3, 128 -> 64 channels (two-pointer concat of 64 + 64, or one 128-channel tensor), bf16 tensors,
+    >= 1024 tiles; each workgroup owns half of the output channels; statistics of two samples."""
+    from video_diffusion_nnx_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(13)
+    B, Fr, H, W = 2, 32, 64, 64
+    xa = torch.randn(B, Fr, H, W, 64, generator=g)
+    xb = torch.randn(B, Fr, H, W, 64, generator=g)
+    xb[1] *= 0.5
+    kern = torch.randn(1, 3, 3, 128, 64, generator=g) / (9 * 128) ** 0.5
+    bias = torch.randn(64, generator=g)
+    pw = ops.pack_conv_weights(kern.to(dev), 'bf16')
+    stats = ops.gn_stats_zeros(B, 8, dev)
+    if concat:
+        y = ops.conv_forward(xa.to(dev).to(torch.bfloat16), pw, 64, mode='bf16', bias=bias.to(dev), x1=xb.to(dev).to(torch.bfloat16),
+                             out_stats=stats, y_bf16=True)
+    else:
+        y = ops.conv_forward(torch.cat((xa, xb), -1).to(dev).to(torch.bfloat16), pw, 64, mode='bf16', bias=bias.to(dev), out_stats=stats, y_bf16=True)
+    torch.cuda.synchronize()
+    ref = R.conv_1kk(_bf16r(torch.cat((xa, xb), -1)).double(), _bf16r(kern).double(), bias.double())
+    assert _rel(y.float().cpu().double(), ref) < 4e-3
+    s = ops.gn_stats_reduce(stats, B, 8).cpu()
+    yg = ref.reshape(B, -1, 8, 8)
+    np.testing.assert_allclose(s[..., 0], yg.sum(dim=(1, 3)), rtol=2e-3, atol=5.0)
+    np.testing.assert_allclose(s[..., 1], (yg * yg).sum(dim=(1, 3)), rtol=2e-3)

@@ -578,6 +578,172 @@ static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
     return a.x0_bf16 ? launch(conv64p_kernel<true>) : launch(conv64p_kernel<false>);
 }
 
+// ---- persistent 3x3 conv with Cin = 128 (two-pointer concat of 64 + 64, or one 128-channel tensor), Cout = 64, bf16 inputs ----
+// Same scheme as conv64p_kernel, but a workgroup owns HALF of the output channels (32 x 128 x 9 bf16 weights = 72 KB resident);
+// workgroups 2r and 2r+1 walk the same tile range, so the second reader of a tile finds it in L2.  The 128-channel halo tile
+// (two 64-channel planes, 81 KB) is single-buffered: the next tile is fetched into registers during the MFMAs and written
+// after them.  No prologue (these are the first convs of ResnetBlocks whose input is a concat).
+constexpr int C128_WPL = 9 * 32 * 128;                // bytes per weight plane [9 taps x 32 rows][128 B]
+constexpr int C128_APL = C64_HALO * 128;              // bytes per activation plane
+
+__global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
+    using M = Mma<MODE_BF16>;
+    constexpr int NPIECE = C64_HALO * 16;              // 16-byte pieces of 8 bf16 channels
+    constexpr int NU = (NPIECE + 511) / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Wl = smem;                                   // [2 planes][288 rows][128 B]
+    char* Al = Wl + 2 * C128_WPL;                      // [2 planes][324 rows][128 B]
+    float* chs = reinterpret_cast<float*>(Al + 2 * C128_APL);   // [2][32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    const int half = blockIdx.x & 1, co0 = half * 32;
+    const int tiles_x = P.W >> 4, tiles_pf = tiles_x * (P.H >> 4);
+    const int t0 = (blockIdx.x >> 1) * tiles_per_block, t1 = min(t0 + tiles_per_block, total_tiles);
+    if (t0 >= t1) return;
+
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x0), 0, P.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x1 ? P.x1 : P.x0), 0, P.x1 ? P.x1_bytes : P.x0_bytes, 0x00020000);
+    for (int i = tid; i < 9 * 32 * 16; i += 512) {     // packed [tap][64 co][128 ci] bf16: 256-byte rows
+        const int row = i >> 4, c = i & 15;            // row = tap * 32 + local co
+        const int tap = row >> 5, col = row & 31;
+        const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) + ((size_t)(tap * 64 + co0 + col) * 256) + c * 16);
+        *reinterpret_cast<uint4*>(Wl + (c >> 3) * C128_WPL + swz(row, c & 7)) = v;
+    }
+    if (tid < 64) chs[tid] = 0.f;
+
+    int piy[NU], pix_[NU], ploff[NU], pch[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i = tid + 512 * u;
+        const int hp = min(i >> 4, C64_HALO - 1), pc = i & 15;
+        piy[u] = (i < NPIECE) ? hp / 18 : -100;
+        pix_[u] = hp % 18;
+        pch[u] = pc * 8;                               // channel of the concat
+        ploff[u] = (pc >> 3) * C128_APL + swz(hp, pc & 7);
+    }
+    auto decode = [&](int t, int& f, int& ty, int& tx) { f = t / tiles_pf; const int r = t - f * tiles_pf; ty = r / tiles_x; tx = r - ty * tiles_x; };
+    u32x4 sreg[NU];
+    auto stage_load = [&](int t) {
+        int f, ty, tx; decode(t, f, ty, tx);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int gy = ty * 16 - 1 + piy[u], gx = tx * 16 - 1 + pix_[u];
+            const bool ok = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+            const int pixel = (f * P.H + gy) * P.W + gx;
+            const bool second = P.C1 && pch[u] >= P.C0;
+            const unsigned off = !ok ? OOB : (second ? (unsigned)(pixel * P.C1 + pch[u] - P.C0) * 2u : (unsigned)(pixel * P.C0 + pch[u]) * 2u);
+            sreg[u] = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) if (piy[u] >= 0) *reinterpret_cast<u32x4*>(Al + ploff[u]) = sreg[u];
+    };
+    f32x4 ssum[2], ssq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ssum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    auto flush_stats = [&](int b) {
+        if (!P.out_stats) return;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s1 = reduce16(ssum[tm][e]), s2 = reduce16(ssq[tm][e]);
+                if (lp == 0) { atomicAdd(&chs[tm * 16 + 4 * q + e], s1); atomicAdd(&chs[32 + tm * 16 + 4 * q + e], s2); }
+                ssum[tm][e] = 0.f; ssq[tm][e] = 0.f;
+            }
+        __syncthreads();
+        const int cpg = 64 / P.out_groups, ng = 32 / cpg;       // groups inside this half
+        if (tid < 2 * ng) {
+            const int g = tid >> 1, which = tid & 1;
+            float t = 0.f;
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) t += chs[which * 32 + c];
+            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + ((blockIdx.x >> 1) % GN_SLOTS)) * P.out_groups + half * ng + g) * 2 + which, (double)t);
+        }
+        __syncthreads();
+        if (tid < 64) chs[tid] = 0.f;
+        __syncthreads();
+    };
+    int hpb[2];
+    hpb[0] = (2 * wave) * 18 + lp; hpb[1] = hpb[0] + 18;
+    float4 bias4[2];
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm) bias4[tm] = P.bias ? *reinterpret_cast<const float4*>(P.bias + co0 + tm * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int fcur, tyc, txc;
+    decode(t0, fcur, tyc, txc);
+    int bcur = fcur / P.F;
+    stage_load(t0);
+    stage_store();
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        int fn = fcur, tyn = tyc, txn = txc, bn = bcur;
+        if (more) { stage_load(t + 1); decode(t + 1, fn, tyn, txn); bn = fn / P.F; }
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            int boff[2];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) { const int hp = hpb[tn] + dy * 18 + dx; boff[tn] = swz(hp, q); }
+            const int woff = swz(tap * 32 + lp, q);
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    uint4 af[2], bf[2];
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm) af[tm] = *reinterpret_cast<const uint4*>(Wl + pl * C128_WPL + ((woff + tm * 16 * 128) ^ (ch * 64)));
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(Al + pl * C128_APL + (boff[tn] ^ (ch * 64)));
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
+                }
+        }
+        {
+            const int oy0 = tyc * 16 + 2 * wave, ox = txc * 16 + lp;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const size_t gout = ((size_t)(fcur * P.H + oy0 + tn) * P.W + ox) * 64 + co0;
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    const float4 v = make_float4(acc[tm][tn][0] + bias4[tm].x, acc[tm][tn][1] + bias4[tm].y, acc[tm][tn][2] + bias4[tm].z, acc[tm][tn][3] + bias4[tm].w);
+                    store4_f32_or_bf16(P.y, gout + tm * 16 + 4 * q, v, P.y_bf16);
+                    ssum[tm][0] += v.x; ssum[tm][1] += v.y; ssum[tm][2] += v.z; ssum[tm][3] += v.w;
+                    ssq[tm][0] += v.x * v.x; ssq[tm][1] += v.y * v.y; ssq[tm][2] += v.z * v.z; ssq[tm][3] += v.w * v.w;
+                }
+            }
+        }
+        if (more && bn != bcur) { flush_stats(bcur); bcur = bn; }
+        __syncthreads();                               // every wave is done reading the tile
+        if (more) stage_store();
+        fcur = fn; tyc = tyn; txc = txn;
+        __syncthreads();
+    }
+    flush_stats(bcur);
+}
+
+static hipError_t launch_conv128x64p(const ConvArgs& a, hipStream_t st) {
+    const int total = a.NF * (a.H >> 4) * (a.W >> 4);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const int ranges = std::max(1, std::min(total, cus / 2));
+    const int tpb = (total + ranges - 1) / ranges;
+    const int nranges = (total + tpb - 1) / tpb;
+    const size_t lds = 2 * (size_t)C128_WPL + 2 * (size_t)C128_APL + 64 * 4;
+    auto kfn = conv128x64p_kernel;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kfn, dim3(2 * nranges), dim3(512), lds, st, a, tpb, total);
+    return hipGetLastError();
+}
+
 // Flax kernel [taps][Cin][Cout] fp32  ->  packed [taps][Cout][CinPad] in the MMA element type, zero padded.
 template <int MODE>
 __global__ void pack_weights_kernel(const float* __restrict__ src, void* __restrict__ dst, int taps, int Cin, int Cout, int CinPad) {
@@ -708,6 +874,11 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
             a.wrows == 64 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
             (!a.out_stats || (a.out_groups <= 32 && 64 % a.out_groups == 0)))
             return launch_conv64p(a, st);
+        const bool in16c = a.x0_bf16 && (!a.C1 || a.x1_bf16);
+        if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.Cout == 64 && in16c && !a.pro &&
+            ((a.C0 == 64 && a.C1 == 64) || (a.C0 == 128 && a.C1 == 0)) && a.wrows == 64 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 &&
+            tiles >= 1024 && (!a.out_stats || (a.out_groups <= 32 && 32 % (64 / a.out_groups) == 0 && 64 % a.out_groups == 0)))
+            return launch_conv128x64p(a, st);
     }
     // variant: 64-channel tiles take 256 pixels per workgroup (stride 1) so every wave owns a 64x64 tile
     const int BC = a.Cout <= 64 ? 64 : 128;
