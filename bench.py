@@ -116,6 +116,9 @@ def time_conv_kernels(unet, frames, size, batch, mode, act='f32', reps=5):
         if (mode == 'bf16' and kind in ('c3', 'c3p') and cin == 64 and cout == 64 and s % 16 == 0
                 and batch * frames * (s // 16) ** 2 >= 1024):                            # launch_conv's persistent level-0 specialisation
             sym = f'vdx::conv64p_kernel<{"true" if act == "bf16" else "false"}>'
+        if (mode == 'bf16' and act == 'bf16' and kind == 'c3' and cin == 128 and cout == 64 and s % 16 == 0
+                and batch * frames * (s // 16) ** 2 >= 1024):
+            sym = 'vdx::conv128x64p_kernel'
         launches = 4 if kind == 'up' else 1                                              # the 4 phases are one launch (grid.z)
         d = per_symbol.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
         d['ms'] += ms; d['flops'] += conv_flops(layer, frames, batch); d['bytes'] += conv_bytes(layer, frames, batch, mode, act); d['launches'] += 1
