@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
             {
                 int nh = h, nk = kt + 1;
                 if (nk == nkt) { nk = 0; nh = h + 1; }
-                if (nh < P.heads && !(P.dbg & 2)) wfetch(nh, nk);
+                if (nh < P.heads) wfetch(nh, nk);
             }
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
@@ -388,11 +388,11 @@ __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
         if (co >= P.C || ro < 0) continue;
         const float4 bo = *reinterpret_cast<const float4*>(P.bo + co);
         float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(P.dbg & 4)) xr = load4_f32_or_bf16(P.x, (size_t)(ro + co), P.io_bf16);
+        xr = load4_f32_or_bf16(P.x, (size_t)(ro + co), P.io_bf16);
         float4 v;
         v.x = oacc[tm][0] + bo.x + xr.x; v.y = oacc[tm][1] + bo.y + xr.y;
         v.z = oacc[tm][2] + bo.z + xr.z; v.w = oacc[tm][3] + bo.w + xr.w;
-        if (!(P.dbg & 8)) store4_f32_or_bf16(P.y, (size_t)(ro + co), v, P.io_bf16);
+        store4_f32_or_bf16(P.y, (size_t)(ro + co), v, P.io_bf16);
     }
 }
 
@@ -692,7 +692,6 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_attention(int mode, AttnArgs a, hipStream_t st) {
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("VDX_ATTN_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
     a.CPad = conv_cin_pad(mode, a.C);
     a.HDPad = conv_cin_pad(mode, a.heads * 32);
     return mode == MODE_F32 ? launch_attn_m<MODE_F32>(a, st) : launch_attn_m<MODE_BF16>(a, st);

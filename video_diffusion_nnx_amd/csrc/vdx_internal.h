@@ -79,7 +79,6 @@ struct AttnArgs {
     float scale;
     int io_bf16;                              // x and y stored as bf16 (bf16 activation storage); strides stay in elements
     int CPad, HDPad;                          // completed by the launcher
-    int dbg;                                  // timing-only ablation bits (env VDX_ATTN_DBG); 0 in normal use
 };
 hipError_t launch_attention(int mode, AttnArgs a, hipStream_t st);
 
