@@ -265,6 +265,10 @@ int vdx_attention_core_backward_ex(const float* qkv, const float* d_o, float* o,
 size_t vdx_sla_backward_scratch_floats(int nframes, int heads);
 int vdx_sla_core_backward(const float* q, const float* k, const float* v, const float* d_out, float* o, float* dq, float* dk, float* dv,
                           float* scratch, int nframes, int npix, int heads, void* stream);
+/* Same with a choice of arithmetic for the per-(frame, head) reductions (softmax-over-pixels statistics, ctx, dctx):
+ * bf16_operands != 0 = bf16 MFMA with fp32 accumulate (what a VDX_MODE_BF16 handle's backward uses); 0 = exact fp32. */
+int vdx_sla_core_backward_ex(const float* q, const float* k, const float* v, const float* d_out, float* o, float* dq, float* dk, float* dv,
+                             float* scratch, int nframes, int npix, int heads, int bf16_operands, void* stream);
 
 /* out[c] += sum_rows x[row][c]  (bias gradients). */
 int vdx_colsum(const float* x, float* out, long rows, int c, void* stream);

@@ -195,3 +195,8 @@ def test_sla_core_backward(NF, H, W):
     assert _rel(o.cpu().double(), out.detach()) < 1e-5
     for got, ref, nm in ((dq, gq, 'dq'), (dk, gk, 'dk'), (dv, gv, 'dv')):
         assert _rel(got.cpu().double(), ref) < 3e-5, (nm, _rel(got.cpu().double(), ref))
+    # bf16-operand reductions (pass A on MFMA; pass B unchanged): what a bf16-mode handle's backward uses
+    o, dq, dk, dv = ops.sla_core_backward(f(q), f(k), f(v), f(d_out), NF, N, bf16_operands=True)
+    assert _rel(o.cpu().double(), out.detach()) < 1e-2
+    for got, ref, nm in ((dq, gq, 'dq'), (dk, gk, 'dk'), (dv, gv, 'dv')):
+        assert _rel(got.cpu().double(), ref) < 2e-2, ('bf16', nm, _rel(got.cpu().double(), ref))

@@ -247,6 +247,155 @@ __global__ __launch_bounds__(256) void sla_bwd_a_kernel(SlaBwdArgs P) {
     if (tid < 32) { out[2048 + tid] = kmax[tid]; out[2048 + 32 + tid] = ksum[tid]; }
 }
 
+// ---- bf16-mode form of pass A: the two 32x32 reductions over the pixels of a (frame, head) on MFMA ----------------------------
+// Wave w of the 4-wave workgroup takes the 32-pixel tiles w, w+4, ... .  Phase 1: column maxima of k.  Phase 2 per tile: exp(k - max),
+// v, softmax_D(q) and dOut are rounded to bf16 into four [32 pixels][32] LDS images (wave-private) and
+//   ctx_un[d,e] += sum_n exp(k)[n,d] v[n,e],   dctx[d,e] += sum_n qsm[n,d] dOut[n,e]
+// are eight v_mfma_f32_16x16x32_bf16 whose K-strided fragments are transposing LDS reads (ds_read_b64_tr_b16), as in
+// conv_wgrad16_kernel; the column sums of exp(k) are a by-product.  The waves' partial tiles meet in LDS; ctx = ctx_un / ksum.
+constexpr int SA_RS = 32 * 2 + 16;           // bytes per pixel row of an image
+
+__device__ __forceinline__ bf16x8 sa_frag(const char* r0, const char* r1) {
+    typedef short s16x8t __attribute__((ext_vector_type(8)));
+    const s16x4b lo = tr_read4(r0), hi = tr_read4(r1);
+    const s16x8t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+// max / sum over the 8 lanes {l ^ 8, l ^ 16, l ^ 32 combinations} that share (lane & 7)
+__device__ __forceinline__ float colred_max(float v) {
+    v = fmaxf(v, dpp_row<0x128>(v));                          // row_ror:8 = lane ^ 8 inside a 16-lane row
+    return max_q(v);
+}
+__device__ __forceinline__ float colred_sum(float v) {
+    v += dpp_row<0x128>(v);
+    return reduce_q(v);
+}
+// sum / max over the 8 lanes that share (lane >> 3): lane ^ 1, ^ 2 (quad_perm), ^ 4 (row_half_mirror on quad-uniform values)
+__device__ __forceinline__ float rowred_max(float v) {
+    v = fmaxf(v, dpp_row<0xB1>(v)); v = fmaxf(v, dpp_row<0x4E>(v)); return fmaxf(v, dpp_row<0x141>(v));
+}
+__device__ __forceinline__ float rowred_sum(float v) {
+    v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v); return v + dpp_row<0x141>(v);
+}
+
+__global__ __launch_bounds__(256) void sla_bwd_a16_kernel(SlaBwdArgs P) {
+    __shared__ __attribute__((aligned(16))) char imgs[4][4][32 * SA_RS];      // [wave][ks, v, qs, dOut]
+    __shared__ float part[4][2][1024];                                        // per-wave ctx_un / dctx tiles
+    __shared__ float kmx[4][32], ksm[4][32];
+    __shared__ float kmax[32], ksum[32];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    const int rg = lane >> 3, pc = lane & 7;                  // staging: pixel row rg + 8u, channels 4pc..4pc+3
+    const int h = blockIdx.y, n = blockIdx.x;
+    const size_t base = (size_t)n * P.N * 256 + h * 32 + pc * 4;
+    const int ntiles = (P.N + 31) / 32;
+    const float L2E = 1.44269504088896f;
+    // ---- phase 1: column maxima of k ----
+    float4 mx = make_float4(-1e30f, -1e30f, -1e30f, -1e30f);
+    for (int t = w; t < ntiles; t += 4)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = t * 32 + rg + 8 * u;
+            if (p < P.N) {
+                const float4 kv = *reinterpret_cast<const float4*>(P.k + base + (size_t)p * 256);
+                mx.x = fmaxf(mx.x, kv.x); mx.y = fmaxf(mx.y, kv.y); mx.z = fmaxf(mx.z, kv.z); mx.w = fmaxf(mx.w, kv.w);
+            }
+        }
+    mx.x = colred_max(mx.x); mx.y = colred_max(mx.y); mx.z = colred_max(mx.z); mx.w = colred_max(mx.w);
+    if (rg == 0) *reinterpret_cast<float4*>(&kmx[w][pc * 4]) = mx;
+    __syncthreads();
+    if (tid < 32) kmax[tid] = fmaxf(fmaxf(kmx[0][tid], kmx[1][tid]), fmaxf(kmx[2][tid], kmx[3][tid]));
+    __syncthreads();
+    const float4 km = *reinterpret_cast<const float4*>(&kmax[pc * 4]);
+    // ---- phase 2 ----
+    char* Ki = imgs[w][0]; char* Vi = imgs[w][1]; char* Qi = imgs[w][2]; char* Di = imgs[w][3];
+    f32x4 cacc[2][2], dacc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { cacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; dacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float4 ks4 = make_float4(0.f, 0.f, 0.f, 0.f);            // column sums of exp(k - max), this lane's rows
+    // transposing-read roles: group q supplies pixels 8q..8q+7 of the tile; in-group lane 4*qr + cc -> pixel 8q + qr (+4), 8-byte chunk cc
+    const int troff0 = (8 * q + (r >> 2)) * SA_RS + (r & 3) * 8, troff1 = troff0 + 4 * SA_RS;
+    for (int t = w; t < ntiles; t += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = rg + 8 * u, p = t * 32 + row;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv, dv = kv, qv = make_float4(-1e30f, -1e30f, -1e30f, -1e30f);
+            const bool ok = p < P.N;
+            if (ok) {
+                const size_t o = base + (size_t)p * 256;
+                kv = *reinterpret_cast<const float4*>(P.k + o); vv = *reinterpret_cast<const float4*>(P.v + o);
+                qv = *reinterpret_cast<const float4*>(P.q + o); dv = *reinterpret_cast<const float4*>(P.dOut + o);
+                kv.x = __builtin_amdgcn_exp2f((kv.x - km.x) * L2E); kv.y = __builtin_amdgcn_exp2f((kv.y - km.y) * L2E);
+                kv.z = __builtin_amdgcn_exp2f((kv.z - km.z) * L2E); kv.w = __builtin_amdgcn_exp2f((kv.w - km.w) * L2E);
+                ks4.x += kv.x; ks4.y += kv.y; ks4.z += kv.z; ks4.w += kv.w;
+            }
+            // softmax over the 32 channels of this pixel: 8 lanes x 4 values
+            const float m = rowred_max(fmaxf(fmaxf(qv.x, qv.y), fmaxf(qv.z, qv.w)));
+            float4 e;
+            e.x = __builtin_amdgcn_exp2f((qv.x - m) * L2E); e.y = __builtin_amdgcn_exp2f((qv.y - m) * L2E);
+            e.z = __builtin_amdgcn_exp2f((qv.z - m) * L2E); e.w = __builtin_amdgcn_exp2f((qv.w - m) * L2E);
+            const float inv = ok ? __builtin_amdgcn_rcpf(rowred_sum(e.x + e.y + e.z + e.w)) : 0.f;
+            const int lo = row * SA_RS + pc * 8;
+            *reinterpret_cast<uint2*>(Ki + lo) = make_uint2(pack_bf16x2(kv.x, kv.y), pack_bf16x2(kv.z, kv.w));
+            *reinterpret_cast<uint2*>(Vi + lo) = make_uint2(pack_bf16x2(vv.x, vv.y), pack_bf16x2(vv.z, vv.w));
+            *reinterpret_cast<uint2*>(Qi + lo) = make_uint2(pack_bf16x2(e.x * inv, e.y * inv), pack_bf16x2(e.z * inv, e.w * inv));
+            *reinterpret_cast<uint2*>(Di + lo) = make_uint2(pack_bf16x2(dv.x, dv.y), pack_bf16x2(dv.z, dv.w));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        bf16x8 ka[2], qa[2], vb[2], db[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ka[i] = sa_frag(Ki + troff0 + i * 32, Ki + troff1 + i * 32);      // rows d of tile i, K = pixels
+            qa[i] = sa_frag(Qi + troff0 + i * 32, Qi + troff1 + i * 32);
+            vb[i] = sa_frag(Vi + troff0 + i * 32, Vi + troff1 + i * 32);      // K = pixels, columns e of tile i
+            db[i] = sa_frag(Di + troff0 + i * 32, Di + troff1 + i * 32);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                cacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[i], vb[j], cacc[i][j], 0, 0, 0);
+                dacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[i], db[j], dacc[i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    // ---- combine the 4 waves ----
+    ks4.x = colred_sum(ks4.x); ks4.y = colred_sum(ks4.y); ks4.z = colred_sum(ks4.z); ks4.w = colred_sum(ks4.w);
+    if (rg == 0) *reinterpret_cast<float4*>(&ksm[w][pc * 4]) = ks4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {                     // accumulator (col r, rows 4q+e) -> [d][e] row-major
+                part[w][0][(i * 16 + 4 * q + e) * 32 + j * 16 + r] = cacc[i][j][e];
+                part[w][1][(i * 16 + 4 * q + e) * 32 + j * 16 + r] = dacc[i][j][e];
+            }
+    __syncthreads();
+    if (tid < 32) ksum[tid] = ksm[0][tid] + ksm[1][tid] + ksm[2][tid] + ksm[3][tid];
+    __syncthreads();
+    float* out = P.A + ((size_t)n * P.heads + h) * SLA_A;
+    const int pd = tid >> 3, e0 = (tid & 7) * 4;              // this thread: ctx[pd][e0..e0+3]
+    float tsum = 0.f;
+    const float isum = 1.0f / ksum[pd];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = pd * 32 + e0 + e;
+        const float c = (part[0][0][i] + part[1][0][i] + part[2][0][i] + part[3][0][i]) * isum;
+        const float dc = part[0][1][i] + part[1][1][i] + part[2][1][i] + part[3][1][i];
+        out[i] = c; out[1024 + i] = dc; tsum += c * dc;
+    }
+    tsum += __shfl_xor(tsum, 1); tsum += __shfl_xor(tsum, 2); tsum += __shfl_xor(tsum, 4);
+    if ((tid & 7) == 0) out[2048 + 64 + pd] = tsum;
+    if (tid < 32) { out[2048 + tid] = kmax[tid]; out[2048 + 32 + tid] = ksum[tid]; }
+}
+
 // pass B: one thread = one pixel (all 32 channels of a head), loop over heads: out (forward, for dWout), dq, dk, dv
 __global__ __launch_bounds__(256) void sla_bwd_b_kernel(SlaBwdArgs P) {
     __shared__ float ctx[32][33], dctx[32][33];
@@ -337,7 +486,8 @@ hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st) {
 size_t sla_bwd_scratch_floats(int NF, int heads) { return (size_t)NF * heads * SLA_A; }
 
 hipError_t launch_sla_bwd(const SlaBwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(sla_bwd_a_kernel, dim3(a.NF, a.heads), dim3(256), 0, st, a);
+    if (a.bf16_mma) hipLaunchKernelGGL(sla_bwd_a16_kernel, dim3(a.NF, a.heads), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(sla_bwd_a_kernel, dim3(a.NF, a.heads), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int tiles = (a.N + 255) / 256;

@@ -163,6 +163,7 @@ void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, fl
     memset(&a, 0, sizeof(a));
     a.q = q; a.k = k; a.v = v; a.dOut = dOut; a.O = O; a.dq = dq; a.dk = dk; a.dv = dv; a.A = b.sla_a;
     a.NF = b.B * m->cfg.num_frames; a.N = b.size(lvl) * b.size(lvl); a.heads = m->cfg.attn_heads;
+    a.bf16_mma = (m->mode == MODE_BF16);
     b.ok(launch_sla_bwd(a, b.st));
     wgrad1x1(b, O, HD, g, C, sp.o_w, -1, lvl);
     float* d3[3] = {dq, dk, dv};

@@ -416,10 +416,16 @@ size_t vdx_sla_backward_scratch_floats(int nframes, int heads) { return vdx::sla
 
 int vdx_sla_core_backward(const float* q, const float* k, const float* v, const float* d_out, float* o, float* dq, float* dk, float* dv,
                           float* scratch, int nframes, int npix, int heads, void* stream) {
+    return vdx_sla_core_backward_ex(q, k, v, d_out, o, dq, dk, dv, scratch, nframes, npix, heads, 0, stream);
+}
+
+int vdx_sla_core_backward_ex(const float* q, const float* k, const float* v, const float* d_out, float* o, float* dq, float* dk, float* dv,
+                             float* scratch, int nframes, int npix, int heads, int bf16_operands, void* stream) {
     if (!q || !k || !v || !d_out || !o || !dq || !dk || !dv || !scratch || heads != 8) VDX_FAIL(VDX_ERR_INVALID, "sla_core_backward: bad argument");
     vdx::SlaBwdArgs a;
     memset(&a, 0, sizeof(a));
     a.q = q; a.k = k; a.v = v; a.dOut = d_out; a.O = o; a.dq = dq; a.dk = dk; a.dv = dv; a.A = scratch; a.NF = nframes; a.N = npix; a.heads = heads;
+    a.bf16_mma = bf16_operands ? 1 : 0;
     VDX_HIP(vdx::launch_sla_bwd(a, (hipStream_t)stream));
     return VDX_OK;
 }

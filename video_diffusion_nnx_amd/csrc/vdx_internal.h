@@ -164,6 +164,7 @@ hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st);
 struct SlaBwdArgs {
     const float* q; const float* k; const float* v; const float* dOut; float* O; float* dq; float* dk; float* dv; float* A;
     int NF, N, heads;
+    int bf16_mma;                                 // pass A on bf16 MFMA (bf16 mode) instead of the exact fp32 VALU form
 };
 size_t sla_bwd_scratch_floats(int NF, int heads);
 hipError_t launch_sla_bwd(const SlaBwdArgs& a, hipStream_t st);

@@ -203,7 +203,7 @@ def norm_act_backward(dact, y, stats, gamma, beta, groups=8, scale_shift=None, r
 
 _attn_core_bwd = L._sig('vdx_attention_core_backward_ex', C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7 + [C.c_void_p])
 _sla_scr = L._sig('vdx_sla_backward_scratch_floats', C.c_size_t, [C.c_int, C.c_int])
-_sla_core_bwd = L._sig('vdx_sla_core_backward', C.c_int, [C.c_void_p] * 9 + [C.c_int] * 3 + [C.c_void_p])
+_sla_core_bwd = L._sig('vdx_sla_core_backward_ex', C.c_int, [C.c_void_p] * 9 + [C.c_int] * 4 + [C.c_void_p])
 
 
 def attention_core_backward(qkv, d_o, B, Fr, H, W, heads, temporal, bf16_operands=False):
@@ -213,8 +213,9 @@ def attention_core_backward(qkv, d_o, B, Fr, H, W, heads, temporal, bf16_operand
     return outs      # o, dq, dk, dv
 
 
-def sla_core_backward(q, k, v, d_out, nframes, npix, heads=8):
+def sla_core_backward(q, k, v, d_out, nframes, npix, heads=8, bf16_operands=False):
     outs = [torch.empty_like(q) for _ in range(4)]
     scr = torch.empty(_sla_scr(nframes, heads), dtype=torch.float32, device=q.device)
-    L.check(_sla_core_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(d_out), *[L.ptr(t) for t in outs], L.ptr(scr), nframes, npix, heads, L.stream_ptr()))
+    L.check(_sla_core_bwd(L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(d_out), *[L.ptr(t) for t in outs], L.ptr(scr), nframes, npix, heads,
+                          int(bool(bf16_operands)), L.stream_ptr()))
     return outs      # o, dq, dk, dv
