@@ -467,6 +467,100 @@ __global__ __launch_bounds__(256) void sla_bwd_b_kernel(SlaBwdArgs P) {
     }
 }
 
+// ---- bf16-mode form of pass B: the four 32x32 mat-vecs per (pixel, head) as MFMAs ------------------------------------------------
+// Everything is computed TRANSPOSED so that lane (c, q) of an accumulator owns pixel c and channels 4q..4q+3 (+16): its inputs
+// are two float4 per tensor, its outputs two float4 per tensor, and softmax_D(q) is an in-lane + permlane reduction.
+//   O^T = ctx^T qsm^T,  dqs^T = ctx dOut^T,  dv^T = dctx^T ksm^T,  dks^T = dctx v^T      (A = the per-head 32x32 matrix, B = pixel data)
+// The K slots of a lane are permuted consistently on both operands: slot j of lane group q is channel 4q+j (j<4) / 16+4q+j-4.
+// The eight A fragments of a head are built once per wave from an LDS copy of ctx / dctx and reused for all its pixel tiles.
+__device__ __forceinline__ bf16x8 pack8_bf16(const float4& a, const float4& b) {
+    const uint4 u = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+__global__ __launch_bounds__(256) void sla_bwd_b16_kernel(SlaBwdArgs P) {
+    __shared__ float cm[32][33], dm[32][33];                 // ctx[d][e], dctx[d][e] of the current head
+    __shared__ float km[32], ksu[32], Tv[32];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int c = lane & 15, q = lane >> 4;
+    const int chunks = (P.N + 255) / 256;
+    const int n = blockIdx.x / chunks, p0 = (blockIdx.x % chunks) * 256;
+    const float L2E = 1.44269504088896f;
+    for (int h = 0; h < P.heads; ++h) {
+        const float* A = P.A + ((size_t)n * P.heads + h) * SLA_A;
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 256) { cm[i >> 5][i & 31] = A[i]; dm[i >> 5][i & 31] = A[1024 + i]; }
+        if (tid < 32) { km[tid] = A[2048 + tid]; ksu[tid] = 1.0f / A[2048 + 32 + tid]; Tv[tid] = A[2048 + 64 + tid]; }
+        __syncthreads();
+        // A fragments: row = 16 i + c of the matrix, K slots = this lane group's 8 channels
+        bf16x8 a_ctxT[2], a_ctx[2], a_dctxT[2], a_dctx[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = 16 * i + c;
+            float4 lo, hi;
+            lo = make_float4(cm[4 * q][row], cm[4 * q + 1][row], cm[4 * q + 2][row], cm[4 * q + 3][row]);                          // ctx^T[e=row][d slots]
+            hi = make_float4(cm[16 + 4 * q][row], cm[17 + 4 * q][row], cm[18 + 4 * q][row], cm[19 + 4 * q][row]);
+            a_ctxT[i] = pack8_bf16(lo, hi);
+            lo = make_float4(cm[row][4 * q], cm[row][4 * q + 1], cm[row][4 * q + 2], cm[row][4 * q + 3]);                          // ctx[d=row][e slots]
+            hi = make_float4(cm[row][16 + 4 * q], cm[row][17 + 4 * q], cm[row][18 + 4 * q], cm[row][19 + 4 * q]);
+            a_ctx[i] = pack8_bf16(lo, hi);
+            lo = make_float4(dm[4 * q][row], dm[4 * q + 1][row], dm[4 * q + 2][row], dm[4 * q + 3][row]);
+            hi = make_float4(dm[16 + 4 * q][row], dm[17 + 4 * q][row], dm[18 + 4 * q][row], dm[19 + 4 * q][row]);
+            a_dctxT[i] = pack8_bf16(lo, hi);
+            lo = make_float4(dm[row][4 * q], dm[row][4 * q + 1], dm[row][4 * q + 2], dm[row][4 * q + 3]);
+            hi = make_float4(dm[row][16 + 4 * q], dm[row][17 + 4 * q], dm[row][18 + 4 * q], dm[row][19 + 4 * q]);
+            a_dctx[i] = pack8_bf16(lo, hi);
+        }
+        const float4 km0 = *reinterpret_cast<const float4*>(&km[4 * q]), km1 = *reinterpret_cast<const float4*>(&km[16 + 4 * q]);
+        const float4 ki0 = *reinterpret_cast<const float4*>(&ksu[4 * q]), ki1 = *reinterpret_cast<const float4*>(&ksu[16 + 4 * q]);
+        const float4 T0 = *reinterpret_cast<const float4*>(&Tv[4 * q]), T1 = *reinterpret_cast<const float4*>(&Tv[16 + 4 * q]);
+        for (int t = w; t < 16; t += 4) {                     // 16-pixel tiles of this workgroup's 256 pixels
+            const int p = p0 + t * 16 + c;
+            const bool ok = p < P.N;
+            const size_t o = ((size_t)n * P.N + (ok ? p : 0)) * 256 + h * 32 + 4 * q;
+            float4 q0 = *reinterpret_cast<const float4*>(P.q + o), q1 = *reinterpret_cast<const float4*>(P.q + o + 16);
+            float4 k0 = *reinterpret_cast<const float4*>(P.k + o), k1 = *reinterpret_cast<const float4*>(P.k + o + 16);
+            const float4 v0 = *reinterpret_cast<const float4*>(P.v + o), v1 = *reinterpret_cast<const float4*>(P.v + o + 16);
+            const float4 d0 = *reinterpret_cast<const float4*>(P.dOut + o), d1 = *reinterpret_cast<const float4*>(P.dOut + o + 16);
+            // softmax over the 32 channels of this pixel (8 in-lane, 4 lanes)
+            const float mx = max_q(fmaxf(fmaxf(fmaxf(q0.x, q0.y), fmaxf(q0.z, q0.w)), fmaxf(fmaxf(q1.x, q1.y), fmaxf(q1.z, q1.w))));
+            q0.x = __builtin_amdgcn_exp2f((q0.x - mx) * L2E); q0.y = __builtin_amdgcn_exp2f((q0.y - mx) * L2E);
+            q0.z = __builtin_amdgcn_exp2f((q0.z - mx) * L2E); q0.w = __builtin_amdgcn_exp2f((q0.w - mx) * L2E);
+            q1.x = __builtin_amdgcn_exp2f((q1.x - mx) * L2E); q1.y = __builtin_amdgcn_exp2f((q1.y - mx) * L2E);
+            q1.z = __builtin_amdgcn_exp2f((q1.z - mx) * L2E); q1.w = __builtin_amdgcn_exp2f((q1.w - mx) * L2E);
+            const float inv = __builtin_amdgcn_rcpf(reduce_q(q0.x + q0.y + q0.z + q0.w + q1.x + q1.y + q1.z + q1.w));
+            q0.x *= inv; q0.y *= inv; q0.z *= inv; q0.w *= inv; q1.x *= inv; q1.y *= inv; q1.z *= inv; q1.w *= inv;      // qsm
+            k0.x = __builtin_amdgcn_exp2f((k0.x - km0.x) * L2E) * ki0.x; k0.y = __builtin_amdgcn_exp2f((k0.y - km0.y) * L2E) * ki0.y;
+            k0.z = __builtin_amdgcn_exp2f((k0.z - km0.z) * L2E) * ki0.z; k0.w = __builtin_amdgcn_exp2f((k0.w - km0.w) * L2E) * ki0.w;
+            k1.x = __builtin_amdgcn_exp2f((k1.x - km1.x) * L2E) * ki1.x; k1.y = __builtin_amdgcn_exp2f((k1.y - km1.y) * L2E) * ki1.y;
+            k1.z = __builtin_amdgcn_exp2f((k1.z - km1.z) * L2E) * ki1.z; k1.w = __builtin_amdgcn_exp2f((k1.w - km1.w) * L2E) * ki1.w;      // ksm
+            const bf16x8 bq = pack8_bf16(q0, q1), bk = pack8_bf16(k0, k1), bv = pack8_bf16(v0, v1), bd = pack8_bf16(d0, d1);
+            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 oT[2], dqsT[2], dvT[2], dksT[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                oT[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_ctxT[i], bq, z, 0, 0, 0);
+                dqsT[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_ctx[i], bd, z, 0, 0, 0);
+                dvT[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_dctxT[i], bk, z, 0, 0, 0);
+                dksT[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_dctx[i], bv, z, 0, 0, 0);
+            }
+            float dot = q0.x * dqsT[0][0] + q0.y * dqsT[0][1] + q0.z * dqsT[0][2] + q0.w * dqsT[0][3]
+                      + q1.x * dqsT[1][0] + q1.y * dqsT[1][1] + q1.z * dqsT[1][2] + q1.w * dqsT[1][3];
+            dot = reduce_q(dot);
+            if (ok) {
+                *reinterpret_cast<float4*>(P.O + o) = make_float4(oT[0][0], oT[0][1], oT[0][2], oT[0][3]);
+                *reinterpret_cast<float4*>(P.O + o + 16) = make_float4(oT[1][0], oT[1][1], oT[1][2], oT[1][3]);
+                *reinterpret_cast<float4*>(P.dv + o) = make_float4(dvT[0][0], dvT[0][1], dvT[0][2], dvT[0][3]);
+                *reinterpret_cast<float4*>(P.dv + o + 16) = make_float4(dvT[1][0], dvT[1][1], dvT[1][2], dvT[1][3]);
+                *reinterpret_cast<float4*>(P.dq + o) = make_float4(q0.x * (dqsT[0][0] - dot), q0.y * (dqsT[0][1] - dot), q0.z * (dqsT[0][2] - dot), q0.w * (dqsT[0][3] - dot));
+                *reinterpret_cast<float4*>(P.dq + o + 16) = make_float4(q1.x * (dqsT[1][0] - dot), q1.y * (dqsT[1][1] - dot), q1.z * (dqsT[1][2] - dot), q1.w * (dqsT[1][3] - dot));
+                *reinterpret_cast<float4*>(P.dk + o) = make_float4(k0.x * (dksT[0][0] - T0.x), k0.y * (dksT[0][1] - T0.y), k0.z * (dksT[0][2] - T0.z), k0.w * (dksT[0][3] - T0.w));
+                *reinterpret_cast<float4*>(P.dk + o + 16) = make_float4(k1.x * (dksT[1][0] - T1.x), k1.y * (dksT[1][1] - T1.y), k1.z * (dksT[1][2] - T1.z), k1.w * (dksT[1][3] - T1.w));
+            }
+        }
+    }
+}
+
 hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st) {
     if (a.bf16_mma && a.L <= 16) {
         const long blocks = (a.nseq + 3) / 4;
@@ -491,7 +585,8 @@ hipError_t launch_sla_bwd(const SlaBwdArgs& a, hipStream_t st) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int tiles = (a.N + 255) / 256;
-    hipLaunchKernelGGL(sla_bwd_b_kernel, dim3(a.NF * tiles), dim3(256), 0, st, a);
+    if (a.bf16_mma) hipLaunchKernelGGL(sla_bwd_b16_kernel, dim3(a.NF * tiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(sla_bwd_b_kernel, dim3(a.NF * tiles), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
