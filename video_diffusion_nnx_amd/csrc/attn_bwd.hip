@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(AttnBwdArgs P) {
                 dv = fmaf(Pm[j * LP1 + t], dO[j * LD + d], dv);
             }
             const size_t row = (size_t)(row0 + (long)t * P.tok_p);
-            const size_t o_ = row * HD + h * 32 + d;
-            P.O[o_] = o; P.dq[o_] = dq * P.scale; P.dk[o_] = dk; P.dv[o_] = dv;
+            const size_t o_ = row * HD + h * 32 + d, g_ = row * P.dstride + h * 32 + d;
+            P.O[o_] = o; P.dq[g_] = dq * P.scale; P.dk[g_] = dk; P.dv[g_] = dv;
         }
     }
 }
@@ -174,11 +174,11 @@ __global__ __launch_bounds__(256) void attn_core_bwd16_kernel(AttnBwdArgs P) {
             const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ak, bdST, z, 0, 0, 0);
             const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aq, bdSn, z, 0, 0, 0);
             if (ovalid) {
-                const size_t o_ = orow * HD + h * 32 + t * 16 + 4 * q;
+                const size_t o_ = orow * HD + h * 32 + t * 16 + 4 * q, g_ = orow * P.dstride + h * 32 + t * 16 + 4 * q;
                 *reinterpret_cast<float4*>(P.O + o_) = make_float4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<float4*>(P.dv + o_) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-                *reinterpret_cast<float4*>(P.dq + o_) = make_float4(dq[0] * P.scale, dq[1] * P.scale, dq[2] * P.scale, dq[3] * P.scale);
-                *reinterpret_cast<float4*>(P.dk + o_) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+                *reinterpret_cast<float4*>(P.dv + g_) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+                *reinterpret_cast<float4*>(P.dq + g_) = make_float4(dq[0] * P.scale, dq[1] * P.scale, dq[2] * P.scale, dq[3] * P.scale);
+                *reinterpret_cast<float4*>(P.dk + g_) = make_float4(dk[0], dk[1], dk[2], dk[3]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // images are rewritten for the next head
@@ -412,6 +412,7 @@ __global__ __launch_bounds__(256) void sla_bwd_b_kernel(SlaBwdArgs P) {
         __syncthreads();
         if (!ok) continue;
         const size_t o = ((size_t)n * P.N + p) * 256 + h * 32;
+        const size_t go = ((size_t)n * P.N + p) * P.dstride + h * 32;          // dq / dk / dv rows (possibly one interleaved buffer)
         float q[32], x[32];
         float mx = -1e30f;
 #pragma unroll
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256) void sla_bwd_b_kernel(SlaBwdArgs P) {
         }
 #pragma unroll
         for (int d = 0; d < 32; d += 4) {
-            *reinterpret_cast<float4*>(P.dq + o + d) = make_float4(q[d] * (dqs[d] - dot), q[d + 1] * (dqs[d + 1] - dot), q[d + 2] * (dqs[d + 2] - dot), q[d + 3] * (dqs[d + 3] - dot));
+            *reinterpret_cast<float4*>(P.dq + go + d) = make_float4(q[d] * (dqs[d] - dot), q[d + 1] * (dqs[d + 1] - dot), q[d + 2] * (dqs[d + 2] - dot), q[d + 3] * (dqs[d + 3] - dot));
             *reinterpret_cast<float4*>(P.O + o + d) = make_float4(outv[d], outv[d + 1], outv[d + 2], outv[d + 3]);
         }
         // k side: ksm[d], dksm[d] = sum_e dctx[d][e] v[e], dk = ksm (dksm - T) ; dv[e] = sum_d ksm[d] dctx[d][e]
@@ -461,8 +462,8 @@ __global__ __launch_bounds__(256) void sla_bwd_b_kernel(SlaBwdArgs P) {
         }
 #pragma unroll
         for (int d = 0; d < 32; d += 4) {
-            *reinterpret_cast<float4*>(P.dk + o + d) = make_float4(dqs[d], dqs[d + 1], dqs[d + 2], dqs[d + 3]);
-            *reinterpret_cast<float4*>(P.dv + o + d) = make_float4(outv[d], outv[d + 1], outv[d + 2], outv[d + 3]);
+            *reinterpret_cast<float4*>(P.dk + go + d) = make_float4(dqs[d], dqs[d + 1], dqs[d + 2], dqs[d + 3]);
+            *reinterpret_cast<float4*>(P.dv + go + d) = make_float4(outv[d], outv[d + 1], outv[d + 2], outv[d + 3]);
         }
     }
 }
@@ -518,6 +519,7 @@ __global__ __launch_bounds__(256) void sla_bwd_b16_kernel(SlaBwdArgs P) {
             const int p = p0 + t * 16 + c;
             const bool ok = p < P.N;
             const size_t o = ((size_t)n * P.N + (ok ? p : 0)) * 256 + h * 32 + 4 * q;
+            const size_t go = ((size_t)n * P.N + (ok ? p : 0)) * P.dstride + h * 32 + 4 * q;
             float4 q0 = *reinterpret_cast<const float4*>(P.q + o), q1 = *reinterpret_cast<const float4*>(P.q + o + 16);
             float4 k0 = *reinterpret_cast<const float4*>(P.k + o), k1 = *reinterpret_cast<const float4*>(P.k + o + 16);
             const float4 v0 = *reinterpret_cast<const float4*>(P.v + o), v1 = *reinterpret_cast<const float4*>(P.v + o + 16);
@@ -550,12 +552,12 @@ __global__ __launch_bounds__(256) void sla_bwd_b16_kernel(SlaBwdArgs P) {
             if (ok) {
                 *reinterpret_cast<float4*>(P.O + o) = make_float4(oT[0][0], oT[0][1], oT[0][2], oT[0][3]);
                 *reinterpret_cast<float4*>(P.O + o + 16) = make_float4(oT[1][0], oT[1][1], oT[1][2], oT[1][3]);
-                *reinterpret_cast<float4*>(P.dv + o) = make_float4(dvT[0][0], dvT[0][1], dvT[0][2], dvT[0][3]);
-                *reinterpret_cast<float4*>(P.dv + o + 16) = make_float4(dvT[1][0], dvT[1][1], dvT[1][2], dvT[1][3]);
-                *reinterpret_cast<float4*>(P.dq + o) = make_float4(q0.x * (dqsT[0][0] - dot), q0.y * (dqsT[0][1] - dot), q0.z * (dqsT[0][2] - dot), q0.w * (dqsT[0][3] - dot));
-                *reinterpret_cast<float4*>(P.dq + o + 16) = make_float4(q1.x * (dqsT[1][0] - dot), q1.y * (dqsT[1][1] - dot), q1.z * (dqsT[1][2] - dot), q1.w * (dqsT[1][3] - dot));
-                *reinterpret_cast<float4*>(P.dk + o) = make_float4(k0.x * (dksT[0][0] - T0.x), k0.y * (dksT[0][1] - T0.y), k0.z * (dksT[0][2] - T0.z), k0.w * (dksT[0][3] - T0.w));
-                *reinterpret_cast<float4*>(P.dk + o + 16) = make_float4(k1.x * (dksT[1][0] - T1.x), k1.y * (dksT[1][1] - T1.y), k1.z * (dksT[1][2] - T1.z), k1.w * (dksT[1][3] - T1.w));
+                *reinterpret_cast<float4*>(P.dv + go) = make_float4(dvT[0][0], dvT[0][1], dvT[0][2], dvT[0][3]);
+                *reinterpret_cast<float4*>(P.dv + go + 16) = make_float4(dvT[1][0], dvT[1][1], dvT[1][2], dvT[1][3]);
+                *reinterpret_cast<float4*>(P.dq + go) = make_float4(q0.x * (dqsT[0][0] - dot), q0.y * (dqsT[0][1] - dot), q0.z * (dqsT[0][2] - dot), q0.w * (dqsT[0][3] - dot));
+                *reinterpret_cast<float4*>(P.dq + go + 16) = make_float4(q1.x * (dqsT[1][0] - dot), q1.y * (dqsT[1][1] - dot), q1.z * (dqsT[1][2] - dot), q1.w * (dqsT[1][3] - dot));
+                *reinterpret_cast<float4*>(P.dk + go) = make_float4(k0.x * (dksT[0][0] - T0.x), k0.y * (dksT[0][1] - T0.y), k0.z * (dksT[0][2] - T0.z), k0.w * (dksT[0][3] - T0.w));
+                *reinterpret_cast<float4*>(P.dk + go + 16) = make_float4(k1.x * (dksT[1][0] - T1.x), k1.y * (dksT[1][1] - T1.y), k1.z * (dksT[1][2] - T1.z), k1.w * (dksT[1][3] - T1.w));
             }
         }
     }

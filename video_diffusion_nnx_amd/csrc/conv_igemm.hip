@@ -787,7 +787,11 @@ __global__ void pack_jobs_kernel(const float* __restrict__ params, char* __restr
         const int k = (int)(i % J.Pad);
         const long r = i / J.Pad;
         float v;
-        if (J.kind == 0) {                                    // row = output channel, k = input channel
+        if (J.kind == 3) {                                    // row = input channel, k = (tensor, output channel) of three kernels
+            const int sel = k / J.Cout, kk = k - sel * J.Cout;
+            const float* sp = params + (sel == 0 ? J.src : (sel == 1 ? J.src1 : J.src2));
+            v = (sel < 3) ? sp[(size_t)r * J.Cout + kk] : 0.f;
+        } else if (J.kind == 0) {                             // row = output channel, k = input channel
             const int co = (int)(r % J.Cout), t = (int)(r / J.Cout);
             v = (k < J.Cin) ? src[((size_t)t * J.Cin + k) * J.Cout + co] : 0.f;
         } else {                                              // row = input channel, k = output channel, taps reversed

@@ -11,7 +11,8 @@ struct Slot { std::string name; long floats_per_sample; long offset_per_sample; 
 
 // one tensor of vdx_pack_params / vdx_pack_params_bwd: kind 0 = [taps][Cin][Cout] -> [taps][Cout][Pad] (MFMA element type),
 // 1 = transposed + tap-reversed [taps][Cin (rows)][Pad], 2 = plain fp32 copy of n floats; src in floats, dst in bytes
-struct PackJob { long src, dst, n; int taps, Cin, Cout, Pad, kind, pad_; };
+// 3 = three [Cin][Cout] projection kernels transposed and concatenated along K: [Cin rows][3*Cout] (src, src1, src2)
+struct PackJob { long src, dst, n; int taps, Cin, Cout, Pad, kind, pad_; long src1, src2; };
 
 struct ResP {
     std::string name;
@@ -21,8 +22,8 @@ struct ResP {
     size_t pt_b1 = 0, pt_b2 = 0, pt_rc = 0;                                                                   // transposed packing (backward)
     int s_y1, s_y2, s_rc, s_out, st1, st2;                                                                    // workspace slots / stats slabs
 };
-struct AttnP { std::string name; int C; long norm_s, norm_b, w[3], b[3], o_w, o_b; size_t pk_qkv, pk_bqkv, pk_o; size_t pt_w[3], pt_o; };
-struct SlaP { std::string name; int C; long norm_s, norm_b, w[3], o_w; size_t pk[3], pk_o; size_t pt_w[3], pt_o; };
+struct AttnP { std::string name; int C; long norm_s, norm_b, w[3], b[3], o_w, o_b; size_t pk_qkv, pk_bqkv, pk_o; size_t pt_w[3], pt_o, pt_qkv; };
+struct SlaP { std::string name; int C; long norm_s, norm_b, w[3], o_w; size_t pk[3], pk_o; size_t pt_w[3], pt_o, pt_qkv; };
 struct Level {
     int cin, cout, lvl; ResP res0, res1; bool has_sla; SlaP sla; AttnP attn; bool has_resample; long rs_w, rs_b; size_t pk_rs; size_t pt_rs = 0;
     int s_sla, s_attn, s_rs;

@@ -100,6 +100,7 @@ static AttnP make_attn(Model* m, const std::string& pre, int C) {
     a.pk_bqkv = add_packed(m, (size_t)3 * H * D * 4);
     a.pk_o = add_packed(m, conv_packed_bytes(m->mode, 1, H * D, C));
     for (int i = 0; i < 3; ++i) a.pt_w[i] = add_packed_t(m, conv_packed_bytes(m->mode, 1, H * D, C));      // [C rows][HD]
+    a.pt_qkv = add_packed_t(m, conv_packed_bytes(m->mode, 1, 3 * H * D, C));                                // [C rows][q|k|v]
     a.pt_o = add_packed_t(m, conv_packed_bytes(m->mode, 1, C, H * D));                                       // [HD rows][C]
     a.name = pre;
     return a;
@@ -119,6 +120,7 @@ static SlaP make_sla(Model* m, const std::string& pre, int C) {
     s.o_w = add_param(m, pre + ".fn.fn.to_out.kernel", {1, HD, C});
     s.pk_o = add_packed(m, conv_packed_bytes(m->mode, 1, HD, C));
     for (int i = 0; i < 3; ++i) s.pt_w[i] = add_packed_t(m, conv_packed_bytes(m->mode, 1, HD, C));
+    s.pt_qkv = add_packed_t(m, conv_packed_bytes(m->mode, 1, 3 * HD, C));
     s.pt_o = add_packed_t(m, conv_packed_bytes(m->mode, 1, C, HD));
     s.name = pre;
     return s;
@@ -282,6 +284,10 @@ void model_build_pack_tables(Model* m) {
         PackJob j{}; j.src = src; j.dst = (long)dst; j.taps = taps; j.Cin = cin; j.Cout = cout; j.Pad = pad(cout); j.kind = 1;
         j.n = (long)taps * cin * j.Pad; m->pack_t_jobs.push_back(j);
     };
+    auto cat3 = [&](const long (&w)[3], size_t dst, int c) {      // [c rows][3 * HD], K = (tensor, head channel)
+        PackJob j{}; j.src = w[0]; j.src1 = w[1]; j.src2 = w[2]; j.dst = (long)dst; j.taps = 1; j.Cin = c; j.Cout = HD; j.Pad = pad(3 * HD); j.kind = 3;
+        j.n = (long)c * j.Pad; m->pack_t_jobs.push_back(j);
+    };
     auto res = [&](const ResP& r) {
         fwd(r.b1_w, r.pk_b1, 9, r.cin, r.cout); fwd(r.b2_w, r.pk_b2, 9, r.cout, r.cout);
         bwd(r.b1_w, r.pt_b1, 9, r.cin, r.cout); bwd(r.b2_w, r.pt_b2, 9, r.cout, r.cout);
@@ -295,10 +301,12 @@ void model_build_pack_tables(Model* m) {
             bwd(a.w[i], a.pt_w[i], 1, a.C, HD);
         }
         fwd(a.o_w, a.pk_o, 1, HD, a.C); bwd(a.o_w, a.pt_o, 1, HD, a.C);
+        cat3(a.w, a.pt_qkv, a.C);
     };
     auto sla = [&](const SlaP& s) {
         for (int i = 0; i < 3; ++i) { fwd(s.w[i], s.pk[i], 1, s.C, HD); bwd(s.w[i], s.pt_w[i], 1, s.C, HD); }
         fwd(s.o_w, s.pk_o, 1, HD, s.C); bwd(s.o_w, s.pt_o, 1, HD, s.C);
+        cat3(s.w, s.pt_qkv, s.C);
     };
     m->pack_jobs.clear(); m->pack_t_jobs.clear();
     attn(m->init_attn);

@@ -123,29 +123,39 @@ void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w
     b.ok(launch_conv_wgrad(a, b.st));
 }
 
+// the q, k and v projection weight gradients of one block in ONE launch: dy = [rows][dq | dk | dv], x read once
+void wgrad1x1_qkv(Bwd& b, const float* x, int cin, const float* dqkv, int hd, const long (&w_off)[3], const long* b_off, int lvl) {
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x0 = x; a.C0 = cin; a.dy = dqkv; a.Cout = 3 * hd; a.split = hd;
+    a.dW = b.grads + w_off[0]; a.dW1 = b.grads + w_off[1]; a.dW2 = b.grads + w_off[2];
+    if (b_off) { a.db = b.grads + b_off[0]; a.db1 = b.grads + b_off[1]; a.db2 = b.grads + b_off[2]; }
+    a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
+    a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
+    a.bf16_mma = (b.m->mode == MODE_BF16);
+    b.ok(launch_conv_wgrad(a, b.st));
+}
+
 // y = MHA(x) + x  backward: g = dL/dy -> out = dL/dx
 void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, bool temporal, float* out) {
     const Model* m = b.m;
     const int C = ap.C, H = m->cfg.attn_heads, HD = H * 32;
     const long npix = b.pix(lvl) * b.B;
-    float* qkv = b.S; float* dO = qkv + npix * 3 * HD; float* O = dO + npix * HD; float* dq = O + npix * HD; float* dk = dq + npix * HD; float* dv = dk + npix * HD;
-    LevelBufs& L = b.lv[lvl];
+    float* qkv = b.S; float* dO = qkv + npix * 3 * HD; float* O = dO + npix * HD; float* dq = O + npix * HD;      // [npix][dq | dk | dv]
     proj(b, x, C, b.pk + ap.pk_qkv, reinterpret_cast<const float*>(b.pk + ap.pk_bqkv), 3 * HD, lvl, nullptr, qkv);
     proj(b, g, C, b.pt + ap.pt_o, nullptr, HD, lvl, nullptr, dO);                                    // dO = g . Wo^T
     AttnBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.qkv = qkv; a.dO = dO; a.O = O; a.dq = dq; a.dk = dk; a.dv = dv; a.heads = H; a.scale = 1.0f / sqrtf((float)m->cfg.attn_dim_head);
+    a.qkv = qkv; a.dO = dO; a.O = O; a.dq = dq; a.dk = dq + HD; a.dv = dq + 2 * HD; a.dstride = 3 * HD;      // one [rows][dq|dk|dv] buffer
+    a.heads = H; a.scale = 1.0f / sqrtf((float)m->cfg.attn_dim_head);
     const long hw = (long)b.size(lvl) * b.size(lvl), Fr = m->cfg.num_frames;
     if (temporal) { a.L = (int)Fr; a.nseq = b.B * hw; a.inner = hw; a.outer_p = Fr * hw; a.tok_p = hw; }
     else { a.L = (int)hw; a.nseq = b.B * Fr; a.inner = 1; a.outer_p = hw; a.tok_p = 1; }
     a.bf16_mma = (m->mode == MODE_BF16);
     b.ok(launch_attn_core_bwd(a, b.st));
     wgrad1x1(b, O, HD, g, C, ap.o_w, ap.o_b, lvl);
-    float* d3[3] = {dq, dk, dv};
-    for (int i = 0; i < 3; ++i) wgrad1x1(b, x, C, d3[i], HD, ap.w[i], ap.b[i], lvl);
-    proj(b, dq, HD, b.pt + ap.pt_w[0], nullptr, C, lvl, g, L.t1);
-    proj(b, dk, HD, b.pt + ap.pt_w[1], nullptr, C, lvl, L.t1, L.t2);
-    proj(b, dv, HD, b.pt + ap.pt_w[2], nullptr, C, lvl, L.t2, out);
+    wgrad1x1_qkv(b, x, C, dq, HD, ap.w, ap.b, lvl);
+    proj(b, dq, 3 * HD, b.pt + ap.pt_qkv, nullptr, C, lvl, g, out);                                  // dx = g + [dq|dk|dv] . [Wq;Wk;Wv]^T
 }
 
 void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, float* out) {
@@ -153,24 +163,20 @@ void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, fl
     const int C = sp.C, HD = m->cfg.attn_heads * 32;
     const long npix = b.pix(lvl) * b.B;
     float* q = b.S; float* k = q + npix * HD; float* v = k + npix * HD; float* dOut = v + npix * HD; float* O = dOut + npix * HD;
-    float* dq = O + npix * HD; float* dk = dq + npix * HD; float* dv = dk + npix * HD;
-    LevelBufs& L = b.lv[lvl];
+    float* dq = O + npix * HD;      // [npix][dq | dk | dv]
     proj(b, x, C, b.pk + sp.pk[0], nullptr, HD, lvl, nullptr, q);
     proj(b, x, C, b.pk + sp.pk[1], nullptr, HD, lvl, nullptr, k);
     proj(b, x, C, b.pk + sp.pk[2], nullptr, HD, lvl, nullptr, v);
     proj(b, g, C, b.pt + sp.pt_o, nullptr, HD, lvl, nullptr, dOut);
     SlaBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = q; a.k = k; a.v = v; a.dOut = dOut; a.O = O; a.dq = dq; a.dk = dk; a.dv = dv; a.A = b.sla_a;
+    a.q = q; a.k = k; a.v = v; a.dOut = dOut; a.O = O; a.dq = dq; a.dk = dq + HD; a.dv = dq + 2 * HD; a.dstride = 3 * HD; a.A = b.sla_a;
     a.NF = b.B * m->cfg.num_frames; a.N = b.size(lvl) * b.size(lvl); a.heads = m->cfg.attn_heads;
     a.bf16_mma = (m->mode == MODE_BF16);
     b.ok(launch_sla_bwd(a, b.st));
     wgrad1x1(b, O, HD, g, C, sp.o_w, -1, lvl);
-    float* d3[3] = {dq, dk, dv};
-    for (int i = 0; i < 3; ++i) wgrad1x1(b, x, C, d3[i], HD, sp.w[i], -1, lvl);
-    proj(b, dq, HD, b.pt + sp.pt_w[0], nullptr, C, lvl, g, L.t1);
-    proj(b, dk, HD, b.pt + sp.pt_w[1], nullptr, C, lvl, L.t1, L.t2);
-    proj(b, dv, HD, b.pt + sp.pt_w[2], nullptr, C, lvl, L.t2, out);
+    wgrad1x1_qkv(b, x, C, dq, HD, sp.w, nullptr, lvl);
+    proj(b, dq, 3 * HD, b.pt + sp.pt_qkv, nullptr, C, lvl, g, out);
 }
 
 float* other(const LevelBufs& L, const float* cur) { return cur == L.ga ? L.gb : L.ga; }

@@ -408,6 +408,7 @@ int vdx_attention_core_backward_ex(const float* qkv, const float* d_o, float* o,
     else { a.L = (int)hw; a.nseq = (long)batch * frames; a.inner = 1; a.outer_p = hw; a.tok_p = 1; }
     if (a.L > 64) VDX_FAIL(VDX_ERR_INVALID, "attention_core_backward: more than 64 tokens per sequence");
     a.bf16_mma = bf16_operands ? 1 : 0;
+    a.dstride = heads * 32;
     VDX_HIP(vdx::launch_attn_core_bwd(a, (hipStream_t)stream));
     return VDX_OK;
 }
@@ -426,6 +427,7 @@ int vdx_sla_core_backward_ex(const float* q, const float* k, const float* v, con
     memset(&a, 0, sizeof(a));
     a.q = q; a.k = k; a.v = v; a.dOut = d_out; a.O = o; a.dq = dq; a.dk = dk; a.dv = dv; a.A = scratch; a.NF = nframes; a.N = npix; a.heads = heads;
     a.bf16_mma = bf16_operands ? 1 : 0;
+    a.dstride = 256;
     VDX_HIP(vdx::launch_sla_bwd(a, (hipStream_t)stream));
     return VDX_OK;
 }

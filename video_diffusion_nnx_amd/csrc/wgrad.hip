@@ -142,7 +142,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
             }
         }
     }
-    if (P.db && do_bias && tid < 64 && co0 + tid < P.Cout) atomicAdd(P.db + co0 + tid, bias_acc);
+    // split > 0: the dY columns of this tile (never straddling: split % 64 == 0) belong to one of up to three weight tensors
+    const int sel = P.split ? co0 / P.split : 0;
+    const int cbase = P.split ? sel * P.split : 0, cw = P.split ? P.split : P.Cout;
+    float* const dWt = sel == 0 ? P.dW : (sel == 1 ? P.dW1 : P.dW2);
+    float* const dbt = sel == 0 ? P.db : (sel == 1 ? P.db1 : P.db2);
+    if (dbt && do_bias && tid < 64 && co0 + tid < P.Cout) atomicAdd(dbt + co0 - cbase + tid, bias_acc);
     // ---- accumulate into dW (Flax layout [taps][Cin][Cout]) ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ci = ci0 + wi * 32 + i * 16 + 4 * q + e;
-                    if (ci < Cin && co < P.Cout) atomicAdd(P.dW + ((size_t)tap * Cin + ci) * P.Cout + co, acc[t][i][j][e]);
+                    if (ci < Cin && co < P.Cout) atomicAdd(dWt + ((size_t)tap * Cin + ci) * cw + co - cbase, acc[t][i][j][e]);
                 }
             }
     }
@@ -319,12 +324,16 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad16_kernel(const WgradArgs 
             }
         }
     }
+    const int sel = P.split ? co0 / P.split : 0;
+    const int cbase = P.split ? sel * P.split : 0, cw = P.split ? P.split : P.Cout;
+    float* const dWt = sel == 0 ? P.dW : (sel == 1 ? P.dW1 : P.dW2);
+    float* const dbt = sel == 0 ? P.db : (sel == 1 ? P.db1 : P.db2);
     if (do_bias) {                                             // (uniform per workgroup)
         const int pc = tid & 15;
         atomicAdd(&bsum[pc * 4 + 0], bias4.x); atomicAdd(&bsum[pc * 4 + 1], bias4.y);
         atomicAdd(&bsum[pc * 4 + 2], bias4.z); atomicAdd(&bsum[pc * 4 + 3], bias4.w);
         __syncthreads();
-        if (tid < 64 && co0 + tid < P.Cout) atomicAdd(P.db + co0 + tid, bsum[tid]);
+        if (dbt && tid < 64 && co0 + tid < P.Cout) atomicAdd(dbt + co0 - cbase + tid, bsum[tid]);
     }
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) {
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad16_kernel(const WgradArgs 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ci = ci0 + wi * 32 + i * 16 + 4 * q + e;
-                    if (ci < Cin && co < P.Cout) atomicAdd(P.dW + ((size_t)tap * Cin + ci) * P.Cout + co, acc[tt][i][j][e]);
+                    if (ci < Cin && co < P.Cout) atomicAdd(dWt + ((size_t)tap * Cin + ci) * cw + co - cbase, acc[tt][i][j][e]);
                 }
             }
     }
