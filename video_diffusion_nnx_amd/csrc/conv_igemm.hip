@@ -776,30 +776,61 @@ __global__ void pack_weights_t_kernel(const float* __restrict__ src, void* __res
     }
 }
 
-// every tensor of a parameter (re)packing in one launch: blockIdx.y = job (model.h PackJob), grid-stride over its elements
+// every tensor of a parameter (re)packing in one launch: blockIdx.y = job (model.h PackJob); a workgroup walks destination rows
+// (one scalar division per row), its threads the contiguous K of the row -- no per-element division
 template <int MODE>
-__global__ void pack_jobs_kernel(const float* __restrict__ params, char* __restrict__ dst_base, const PackJob* __restrict__ jobs) {
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const float* __restrict__ params, char* __restrict__ dst_base, const PackJob* __restrict__ jobs) {
     const PackJob J = jobs[blockIdx.y];
     const float* src = params + J.src;
     char* dstc = dst_base + J.dst;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < J.n; i += (long)gridDim.x * blockDim.x) {
-        if (J.kind == 2) { reinterpret_cast<float*>(dstc)[i] = src[i]; continue; }
-        const int k = (int)(i % J.Pad);
-        const long r = i / J.Pad;
-        float v;
-        if (J.kind == 3) {                                    // row = input channel, k = (tensor, output channel) of three kernels
-            const int sel = k / J.Cout, kk = k - sel * J.Cout;
-            const float* sp = params + (sel == 0 ? J.src : (sel == 1 ? J.src1 : J.src2));
-            v = (sel < 3) ? sp[(size_t)r * J.Cout + kk] : 0.f;
-        } else if (J.kind == 0) {                             // row = output channel, k = input channel
-            const int co = (int)(r % J.Cout), t = (int)(r / J.Cout);
-            v = (k < J.Cin) ? src[((size_t)t * J.Cin + k) * J.Cout + co] : 0.f;
-        } else {                                              // row = input channel, k = output channel, taps reversed
-            const int ci = (int)(r % J.Cin), t = (int)(r / J.Cin);
-            v = (k < J.Cout) ? src[((size_t)(J.taps - 1 - t) * J.Cin + ci) * J.Cout + k] : 0.f;
+    if (J.kind == 2) {                                        // plain copy
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < (int)J.n; i += gridDim.x * 256) reinterpret_cast<float*>(dstc)[i] = src[i];
+        return;
+    }
+    if (J.kind == 0) {                                        // [tap][Cin][Cout] -> [tap][Cout][Pad]: 32 x 32 tiles transposed through LDS
+        __shared__ float tile[32][33];
+        const int tk = (J.Pad + 31) / 32, tc = (J.Cout + 31) / 32, per_tap = tk * tc, ntiles = J.taps * per_tap;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int id = blockIdx.x; id < ntiles; id += gridDim.x) {
+            const int t = id / per_tap, rem = id - t * per_tap, kb = rem / tc, cb = rem - kb * tc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = kb * 32 + ty + 8 * j, co = cb * 32 + tx;
+                tile[ty + 8 * j][tx] = (kk < J.Cin && co < J.Cout) ? src[((size_t)t * J.Cin + kk) * J.Cout + co] : 0.f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = cb * 32 + ty + 8 * j, kk = kb * 32 + tx;
+                if (co < J.Cout && kk < J.Pad) {
+                    const size_t di = ((size_t)t * J.Cout + co) * J.Pad + kk;
+                    const float v = tile[tx][ty + 8 * j];
+                    if (MODE == MODE_F32) reinterpret_cast<float*>(dstc)[di] = v; else reinterpret_cast<__bf16*>(dstc)[di] = (__bf16)v;
+                }
+            }
+            __syncthreads();
         }
-        if (MODE == MODE_F32) reinterpret_cast<float*>(dstc)[i] = v;
-        else reinterpret_cast<__bf16*>(dstc)[i] = (__bf16)v;
+        return;
+    }
+    const int rows = (int)(J.n / J.Pad);
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const size_t drow = (size_t)r * J.Pad;
+        if (false) {
+        } else if (J.kind == 1) {                             // row = (reversed tap, input channel), k = output channel
+            const int t = r / J.Cin, ci = r - t * J.Cin;
+            const float* srow = src + ((size_t)(J.taps - 1 - t) * J.Cin + ci) * J.Cout;
+            for (int k = threadIdx.x; k < J.Pad; k += 256) {
+                const float v = (k < J.Cout) ? srow[k] : 0.f;
+                if (MODE == MODE_F32) reinterpret_cast<float*>(dstc)[drow + k] = v; else reinterpret_cast<__bf16*>(dstc)[drow + k] = (__bf16)v;
+            }
+        } else {                                              // kind 3: row = input channel, k = (tensor, output channel) of three kernels
+            for (int k = threadIdx.x; k < J.Pad; k += 256) {
+                const int sel = k / J.Cout, kk = k - sel * J.Cout;
+                const float* sp = params + (sel == 0 ? J.src : (sel == 1 ? J.src1 : J.src2));
+                const float v = (sel < 3) ? sp[(size_t)r * J.Cout + kk] : 0.f;
+                if (MODE == MODE_F32) reinterpret_cast<float*>(dstc)[drow + k] = v; else reinterpret_cast<__bf16*>(dstc)[drow + k] = (__bf16)v;
+            }
+        }
     }
 }
 
@@ -844,7 +875,7 @@ hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, 
 
 hipError_t launch_pack_jobs(int mode, const float* params, void* dst_base, const PackJob* d_jobs, int njobs, hipStream_t st) {
     if (njobs <= 0) return hipSuccess;
-    dim3 grid(48, njobs);
+    dim3 grid(96, njobs);
     if (mode == MODE_F32) hipLaunchKernelGGL(pack_jobs_kernel<MODE_F32>, grid, dim3(256), 0, st, params, reinterpret_cast<char*>(dst_base), d_jobs);
     else hipLaunchKernelGGL(pack_jobs_kernel<MODE_BF16>, grid, dim3(256), 0, st, params, reinterpret_cast<char*>(dst_base), d_jobs);
     return hipGetLastError();
