@@ -177,46 +177,75 @@ __device__ __forceinline__ float dgelu_tanh_b(float x) {
     return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x * x);
 }
 
-// time MLP backward, single workgroup (tiny): recomputes emb / lin1 / h per sample
+// time MLP backward: workgroup s owns the 64-wide slice [64 s, 64 s + 64) of the hidden dimension (columns of W2 / rows of its
+// transpose / columns of W1).  Every workgroup recomputes emb / lin1 / h of all samples into LDS (tiny); the batch reduction
+// happens in registers, so each weight gets ONE global "+=".
 __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(TimeMlpArgs P, const float* __restrict__ dtemb, float* __restrict__ dw1, float* __restrict__ db1,
                                                            float* __restrict__ dw2, float* __restrict__ db2, float* __restrict__ dnull, int B) {
-    extern __shared__ float sm[];                  // emb[dim] | lin1[td] | h[td] | dlin1[td]
-    float* emb = sm; float* lin1 = emb + P.dim; float* h = lin1 + P.time_dim; float* dl1 = h + P.time_dim;
-    const int tid = threadIdx.x, half = P.dim / 2, td = P.time_dim;
-    for (int b = 0; b < B; ++b) {
-        __syncthreads();
-        const float tval = (float)P.time[b];
-        for (int i = tid; i < half; i += 256) {
-            const float fr = expf((float)i * -(logf(10000.0f) / (float)(half - 1)));
-            emb[i] = sinf(tval * fr); emb[half + i] = cosf(tval * fr);
-        }
-        __syncthreads();
-        for (int n = tid; n < td; n += 256) {
-            float acc = P.b1[n];
-            for (int k = 0; k < P.dim; ++k) acc = fmaf(emb[k], P.w1[(size_t)k * td + n], acc);
-            lin1[n] = acc; h[n] = gelu_tanh_b(acc);
-        }
-        __syncthreads();
-        const float* dt = dtemb + (size_t)b * P.temb_dim;
-        for (int n = tid; n < td; n += 256) {
-            db2[n] += dt[n];
-            for (int k = 0; k < td; ++k) dw2[(size_t)k * td + n] += h[k] * dt[n];
-        }
-        for (int k = tid; k < td; k += 256) {
-            float acc = 0.f;
-            for (int n = 0; n < td; ++n) acc = fmaf(dt[n], P.w2[(size_t)k * td + n], acc);
-            dl1[k] = acc * dgelu_tanh_b(lin1[k]);
-        }
-        __syncthreads();
-        for (int k = tid; k < td; k += 256) {
-            db1[k] += dl1[k];
-            for (int j = 0; j < P.dim; ++j) dw1[(size_t)j * td + k] += emb[j] * dl1[k];
-        }
-        if (P.cond_dim && dnull) {
-            const bool use_null = P.cond_mask ? (P.cond_mask[b] != 0) : (P.null_all != 0);
-            if (use_null) for (int n = tid; n < P.cond_dim; n += 256) dnull[n] += dt[td + n];
+    extern __shared__ float sm[];                  // emb[B][dim] | lin1[B][td] | h[B][td] | dl1[B][64]
+    const int tid = threadIdx.x, half = P.dim / 2, td = P.time_dim, dim = P.dim;
+    float* emb = sm; float* lin1 = emb + (size_t)B * dim; float* h = lin1 + (size_t)B * td; float* dl1 = h + (size_t)B * td;
+    const int n0 = blockIdx.x * 64;
+    for (int i = tid; i < B * half; i += 256) {
+        const int b = i / half, j = i - b * half;
+        const float fr = expf((float)j * -(logf(10000.0f) / (float)(half - 1)));
+        const float arg = (float)P.time[b] * fr;
+        emb[b * dim + j] = sinf(arg); emb[b * dim + half + j] = cosf(arg);
+    }
+    __syncthreads();
+    for (int i = tid; i < B * td; i += 256) {
+        const int b = i / td, n = i - b * td;
+        float acc = P.b1[n];
+        for (int k = 0; k < dim; ++k) acc = fmaf(emb[b * dim + k], P.w1[(size_t)k * td + n], acc);
+        lin1[i] = acc; h[i] = gelu_tanh_b(acc);
+    }
+    __syncthreads();
+    const int col = tid & 63, part = tid >> 6;      // 4 parts
+    {   // dW2[k][n] += sum_b h_b[k] dt_b[n],  db2[n] += sum_b dt_b[n]      for n = n0 + col
+        const int n = n0 + col;
+        if (n < td) {
+            const int kper = (td + 3) / 4;
+            for (int k = part * kper; k < min(td, (part + 1) * kper); ++k) {
+                float acc = 0.f;
+                for (int b = 0; b < B; ++b) acc = fmaf(h[b * td + k], dtemb[(size_t)b * P.temb_dim + n], acc);
+                dw2[(size_t)k * td + n] += acc;
+            }
+            if (part == 0) { float acc = 0.f; for (int b = 0; b < B; ++b) acc += dtemb[(size_t)b * P.temb_dim + n]; db2[n] += acc; }
         }
     }
+    // dl1[b][k] = (sum_n dt_b[n] W2[k][n]) * gelu'(lin1_b[k])      for k = n0 + col, samples strided over the 4 parts
+    for (int b = part; b < B; b += 4) {
+        const int k = n0 + col;
+        float acc = 0.f;
+        if (k < td) {
+            const float* dt = dtemb + (size_t)b * P.temb_dim;
+            for (int n = 0; n < td; ++n) acc = fmaf(dt[n], P.w2[(size_t)k * td + n], acc);
+            acc *= dgelu_tanh_b(lin1[b * td + k]);
+        }
+        dl1[b * 64 + col] = acc;
+    }
+    __syncthreads();
+    {   // db1[k] += sum_b dl1_b[k],  dW1[j][k] += sum_b emb_b[j] dl1_b[k]
+        const int k = n0 + col;
+        if (k < td) {
+            if (part == 0) { float acc = 0.f; for (int b = 0; b < B; ++b) acc += dl1[b * 64 + col]; db1[k] += acc; }
+            const int jper = (dim + 3) / 4;
+            for (int j = part * jper; j < min(dim, (part + 1) * jper); ++j) {
+                float acc = 0.f;
+                for (int b = 0; b < B; ++b) acc = fmaf(emb[b * dim + j], dl1[b * 64 + col], acc);
+                dw1[(size_t)j * td + k] += acc;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && P.cond_dim && dnull)
+        for (int n = tid; n < P.cond_dim; n += 256) {
+            float acc = 0.f;
+            for (int b = 0; b < B; ++b) {
+                const bool use_null = P.cond_mask ? (P.cond_mask[b] != 0) : (P.null_all != 0);
+                if (use_null) acc += dtemb[(size_t)b * P.temb_dim + td + n];
+            }
+            dnull[n] += acc;
+        }
 }
 
 hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, hipStream_t st) {
@@ -254,7 +283,14 @@ hipError_t launch_resblock_ss_bwd(const float* params, float* grads, const float
 }
 
 hipError_t launch_time_mlp_bwd(const TimeMlpArgs& a, const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, float* dnull, int B, hipStream_t st) {
-    hipLaunchKernelGGL(time_mlp_bwd_kernel, dim3(1), dim3(256), (size_t)(a.dim + 3 * a.time_dim) * 4, st, a, dtemb, dw1, db1, dw2, db2, dnull, B);
+    const size_t lds = (size_t)B * (a.dim + 2 * a.time_dim + 64) * 4;
+    if (lds > 150 * 1024) return hipErrorInvalidValue;             // B <= ~60 at the N shape
+    auto kfn = time_mlp_bwd_kernel;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3((a.time_dim + 63) / 64), dim3(256), lds, st, a, dtemb, dw1, db1, dw2, db2, dnull, B);
     return hipGetLastError();
 }
 
