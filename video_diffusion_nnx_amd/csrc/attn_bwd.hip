@@ -102,24 +102,33 @@ __global__ __launch_bounds__(256) void attn_core_bwd16_kernel(AttnBwdArgs P) {
     const int troff = (4 * q + (lp >> 2)) * AB_RS + (lp & 3) * 8;
     const size_t orow = (size_t)(row0 + (long)lp * P.tok_p);          // output: lane (token lp, q) writes channels 4q..4q+3 (+16)
     const bool ovalid = live && lp < P.L;
-    const float L2E = 1.44269504088896f;
+    const float SL2E = P.scale * 1.44269504088896f;           // softmax(scale * s) = exp2((s - max s) * scale * log2 e) / sum
     for (int h = 0; h < P.heads; ++h) {
-        // ---- stage the four images (wave-private: LDS ops of one wave stay in order) ----
+        // ---- stage the four images (wave-private: LDS ops of one wave stay in order).  q stays UNSCALED here: 1/sqrt(d) is folded
+        //      into the exponent of both softmaxes and into the dq / dk outputs ----
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int c = (lq + 4 * u) * 4;
-            float4 vq = make_float4(0.f, 0.f, 0.f, 0.f), vk = vq, vv = vq, vd = vq;
+            uint2 pq = make_uint2(0u, 0u), pk = pq, pv = pq, pd = pq;
             if (rvalid) {
-                const float* src = P.qkv + grow * 3 * HD + h * 32 + c;
-                vq = *reinterpret_cast<const float4*>(src);
-                vk = *reinterpret_cast<const float4*>(src + HD);
-                vv = *reinterpret_cast<const float4*>(src + 2 * HD);
-                vd = *reinterpret_cast<const float4*>(P.dO + grow * HD + h * 32 + c);
+                if (P.io_bf16) {
+                    const char* src = reinterpret_cast<const char*>(P.qkv) + (grow * 3 * HD + h * 32 + c) * 2;
+                    pq = *reinterpret_cast<const uint2*>(src);
+                    pk = *reinterpret_cast<const uint2*>(src + HD * 2);
+                    pv = *reinterpret_cast<const uint2*>(src + 2 * HD * 2);
+                    pd = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.dO) + (grow * HD + h * 32 + c) * 2);
+                } else {
+                    const float* src = P.qkv + grow * 3 * HD + h * 32 + c;
+                    const float4 vq = *reinterpret_cast<const float4*>(src), vk = *reinterpret_cast<const float4*>(src + HD);
+                    const float4 vv = *reinterpret_cast<const float4*>(src + 2 * HD), vd = *reinterpret_cast<const float4*>(P.dO + grow * HD + h * 32 + c);
+                    pq = make_uint2(pack_bf16x2(vq.x, vq.y), pack_bf16x2(vq.z, vq.w)); pk = make_uint2(pack_bf16x2(vk.x, vk.y), pack_bf16x2(vk.z, vk.w));
+                    pv = make_uint2(pack_bf16x2(vv.x, vv.y), pack_bf16x2(vv.z, vv.w)); pd = make_uint2(pack_bf16x2(vd.x, vd.y), pack_bf16x2(vd.z, vd.w));
+                }
             }
-            *reinterpret_cast<uint2*>(Qi + lr * AB_RS + c * 2) = make_uint2(pack_bf16x2(vq.x * P.scale, vq.y * P.scale), pack_bf16x2(vq.z * P.scale, vq.w * P.scale));
-            *reinterpret_cast<uint2*>(Ki + lr * AB_RS + c * 2) = make_uint2(pack_bf16x2(vk.x, vk.y), pack_bf16x2(vk.z, vk.w));
-            *reinterpret_cast<uint2*>(Vi + lr * AB_RS + c * 2) = make_uint2(pack_bf16x2(vv.x, vv.y), pack_bf16x2(vv.z, vv.w));
-            *reinterpret_cast<uint2*>(Di + lr * AB_RS + c * 2) = make_uint2(pack_bf16x2(vd.x, vd.y), pack_bf16x2(vd.z, vd.w));
+            *reinterpret_cast<uint2*>(Qi + lr * AB_RS + c * 2) = pq;
+            *reinterpret_cast<uint2*>(Ki + lr * AB_RS + c * 2) = pk;
+            *reinterpret_cast<uint2*>(Vi + lr * AB_RS + c * 2) = pv;
+            *reinterpret_cast<uint2*>(Di + lr * AB_RS + c * 2) = pd;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -143,7 +152,7 @@ __global__ __launch_bounds__(256) void attn_core_bwd16_kernel(AttnBwdArgs P) {
             mx = max_q(mx);
             float sum = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { PT[e] = __builtin_amdgcn_exp2f((ST[e] - mx) * L2E); sum += PT[e]; }
+            for (int e = 0; e < 4; ++e) { PT[e] = __builtin_amdgcn_exp2f((ST[e] - mx) * SL2E); sum += PT[e]; }
             const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
             float dr = 0.f;
 #pragma unroll
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_core_bwd16_kernel(AttnBwdArgs P) {
         for (int e = 0; e < 4; ++e) {
             const float sv = (lp >= P.L) ? -1e30f : S[e];
             const float mx = max16(sv);
-            const float pe = __builtin_amdgcn_exp2f((sv - mx) * L2E);
+            const float pe = __builtin_amdgcn_exp2f((sv - mx) * SL2E);
             const float pn = pe * __builtin_amdgcn_rcpf(reduce16(pe));
             const float dr = reduce16(dP[e] * pn);
             Pn[e] = pn; dSn[e] = pn * (dP[e] - dr);
@@ -175,10 +184,10 @@ __global__ __launch_bounds__(256) void attn_core_bwd16_kernel(AttnBwdArgs P) {
             const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aq, bdSn, z, 0, 0, 0);
             if (ovalid) {
                 const size_t o_ = orow * HD + h * 32 + t * 16 + 4 * q, g_ = orow * P.dstride + h * 32 + t * 16 + 4 * q;
-                *reinterpret_cast<float4*>(P.O + o_) = make_float4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<float4*>(P.dv + g_) = make_float4(dv[0], dv[1], dv[2], dv[3]);
-                *reinterpret_cast<float4*>(P.dq + g_) = make_float4(dq[0] * P.scale, dq[1] * P.scale, dq[2] * P.scale, dq[3] * P.scale);
-                *reinterpret_cast<float4*>(P.dk + g_) = make_float4(dk[0], dk[1], dk[2], dk[3]);
+                store4_f32_or_bf16(P.O, o_, make_float4(o[0], o[1], o[2], o[3]), P.io_bf16);
+                store4_f32_or_bf16(P.dv, g_, make_float4(dv[0], dv[1], dv[2], dv[3]), P.io_bf16);
+                store4_f32_or_bf16(P.dq, g_, make_float4(dq[0] * P.scale, dq[1] * P.scale, dq[2] * P.scale, dq[3] * P.scale), P.io_bf16);
+                store4_f32_or_bf16(P.dk, g_, make_float4(dk[0] * P.scale, dk[1] * P.scale, dk[2] * P.scale, dk[3] * P.scale), P.io_bf16);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // images are rewritten for the next head

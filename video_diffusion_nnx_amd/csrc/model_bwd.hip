@@ -104,18 +104,21 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
 }
 
 // 1x1 projection  y[pix][cout] = x[pix][cin] . W (+bias) (+res)  with a packed weight
-void proj(Bwd& b, const float* x, int cin, const void* wp, const float* bias, int cout, int lvl, const float* res, float* y) {
+// x_bf16 / y_bf16: the tensor is a bf16 backward intermediate (bf16 mode); a bf16 y excludes res
+void proj(Bwd& b, const float* x, int cin, const void* wp, const float* bias, int cout, int lvl, const float* res, float* y,
+          int x_bf16 = 0, int y_bf16 = 0) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.x0 = x; a.C0 = cin; a.wp = wp; a.bias = bias; a.y = y; a.Cout = cout; a.res = res;
+    a.x0 = x; a.C0 = cin; a.wp = wp; a.bias = bias; a.y = y; a.Cout = cout; a.res = res; a.x0_bf16 = x_bf16; a.y_bf16 = y_bf16;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1; a.pad = 0;
     b.ok(launch_conv(b.m->mode, a, b.st));
 }
 
-void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w_off, long b_off, int lvl) {
+void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w_off, long b_off, int lvl, int x_bf16 = 0) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
+    a.x0_bf16 = x_bf16;
     a.x0 = x; a.C0 = cin; a.dy = dy; a.Cout = cout; a.dW = b.grads + w_off; a.db = b_off >= 0 ? b.grads + b_off : nullptr;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
@@ -124,9 +127,10 @@ void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w
 }
 
 // the q, k and v projection weight gradients of one block in ONE launch: dy = [rows][dq | dk | dv], x read once
-void wgrad1x1_qkv(Bwd& b, const float* x, int cin, const float* dqkv, int hd, const long (&w_off)[3], const long* b_off, int lvl) {
+void wgrad1x1_qkv(Bwd& b, const float* x, int cin, const float* dqkv, int hd, const long (&w_off)[3], const long* b_off, int lvl, int dy_bf16 = 0) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
+    a.dy_bf16 = dy_bf16;
     a.x0 = x; a.C0 = cin; a.dy = dqkv; a.Cout = 3 * hd; a.split = hd;
     a.dW = b.grads + w_off[0]; a.dW1 = b.grads + w_off[1]; a.dW2 = b.grads + w_off[2];
     if (b_off) { a.db = b.grads + b_off[0]; a.db1 = b.grads + b_off[1]; a.db2 = b.grads + b_off[2]; }
@@ -142,20 +146,25 @@ void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, 
     const int C = ap.C, H = m->cfg.attn_heads, HD = H * 32;
     const long npix = b.pix(lvl) * b.B;
     float* qkv = b.S; float* dO = qkv + npix * 3 * HD; float* O = dO + npix * HD; float* dq = O + npix * HD;      // [npix][dq | dk | dv]
-    proj(b, x, C, b.pk + ap.pk_qkv, reinterpret_cast<const float*>(b.pk + ap.pk_bqkv), 3 * HD, lvl, nullptr, qkv);
-    proj(b, g, C, b.pt + ap.pt_o, nullptr, HD, lvl, nullptr, dO);                                    // dO = g . Wo^T
+    // bf16 mode, <= 16 tokens: qkv, dO, O and dq|dk|dv are bf16 tensors (the MFMA core is bound by this traffic); the buffers keep
+    // their fp32-sized places in the scratch
+    const long hw = (long)b.size(lvl) * b.size(lvl), Fr = m->cfg.num_frames;
+    const int io16 = (m->mode == MODE_BF16 && (temporal ? Fr : hw) <= 16) ? 1 : 0;
+    proj(b, x, C, b.pk + ap.pk_qkv, reinterpret_cast<const float*>(b.pk + ap.pk_bqkv), 3 * HD, lvl, nullptr, qkv, 0, io16);
+    proj(b, g, C, b.pt + ap.pt_o, nullptr, HD, lvl, nullptr, dO, 0, io16);                           // dO = g . Wo^T
     AttnBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.qkv = qkv; a.dO = dO; a.O = O; a.dq = dq; a.dk = dq + HD; a.dv = dq + 2 * HD; a.dstride = 3 * HD;      // one [rows][dq|dk|dv] buffer
-    a.heads = H; a.scale = 1.0f / sqrtf((float)m->cfg.attn_dim_head);
-    const long hw = (long)b.size(lvl) * b.size(lvl), Fr = m->cfg.num_frames;
+    a.qkv = qkv; a.dO = dO; a.O = O; a.dq = dq; a.heads = H; a.scale = 1.0f / sqrtf((float)m->cfg.attn_dim_head);
+    a.dstride = 3 * HD; a.io_bf16 = io16;                                                            // one [rows][dq|dk|dv] buffer
+    if (io16) { a.dk = reinterpret_cast<float*>(reinterpret_cast<char*>(dq) + HD * 2); a.dv = reinterpret_cast<float*>(reinterpret_cast<char*>(dq) + 2 * HD * 2); }
+    else { a.dk = dq + HD; a.dv = dq + 2 * HD; }
     if (temporal) { a.L = (int)Fr; a.nseq = b.B * hw; a.inner = hw; a.outer_p = Fr * hw; a.tok_p = hw; }
     else { a.L = (int)hw; a.nseq = b.B * Fr; a.inner = 1; a.outer_p = hw; a.tok_p = 1; }
     a.bf16_mma = (m->mode == MODE_BF16);
     b.ok(launch_attn_core_bwd(a, b.st));
-    wgrad1x1(b, O, HD, g, C, ap.o_w, ap.o_b, lvl);
-    wgrad1x1_qkv(b, x, C, dq, HD, ap.w, ap.b, lvl);
-    proj(b, dq, 3 * HD, b.pt + ap.pt_qkv, nullptr, C, lvl, g, out);                                  // dx = g + [dq|dk|dv] . [Wq;Wk;Wv]^T
+    wgrad1x1(b, O, HD, g, C, ap.o_w, ap.o_b, lvl, io16);
+    wgrad1x1_qkv(b, x, C, dq, HD, ap.w, ap.b, lvl, io16);
+    proj(b, dq, 3 * HD, b.pt + ap.pt_qkv, nullptr, C, lvl, g, out, io16, 0);                          // dx = g + [dq|dk|dv] . [Wq;Wk;Wv]^T
 }
 
 void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, float* out) {

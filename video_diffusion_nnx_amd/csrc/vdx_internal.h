@@ -127,6 +127,7 @@ struct WgradArgs {
     int kind, kh, kw, stride;
     int pro; const double* in_stats; const float* gamma; const float* beta; int groups; const float* ss; int ss_stride;
     int x0_bf16;                                           // x0 stored as bf16
+    int dy_bf16;                                           // dy stored as bf16 (backward intermediates of bf16 mode)
     int split; float* dW1; float* dW2; float* db1; float* db2;   // split > 0: dY column block co / split goes to (dW, dW1, dW2)[co / split], each [taps][Cin][split]
     int bf16_mma;                                          // bf16 MFMA operands (bf16 mode) instead of exact f32
     // completed by the launcher
@@ -158,7 +159,8 @@ hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st);
 struct AttnBwdArgs {
     const float* qkv; const float* dO; float* O; float* dq; float* dk; float* dv;
     int heads, L; long nseq, inner, outer_p, tok_p; float scale;
-    int dstride;                                                     // row stride (floats) of dq / dk / dv: heads*32, or 3*heads*32 for one [rows][dq|dk|dv] buffer
+    int dstride;                                                     // row stride (elements) of dq / dk / dv: heads*32, or 3*heads*32 for one [rows][dq|dk|dv] buffer
+    int io_bf16;                                                     // qkv, dO, O, dq, dk, dv are bf16 tensors (bf16 MFMA form only)
     int bf16_mma;                                                    // bf16 MFMA form (bf16 mode, L <= 16) instead of the exact fp32 VALU form
 };
 hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st);

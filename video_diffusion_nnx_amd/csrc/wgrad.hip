@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
             const int gy = my0 * P.sb + yy, gx = mx0 * P.sb + xx;
             const int c = co0 + pc * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < P.Hy && gx < P.Wy && c < P.Cout) v = *reinterpret_cast<const float4*>(P.dy + (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c);
+            if (gy < P.Hy && gx < P.Wy && c < P.Cout) v = load4_f32_or_bf16(P.dy, (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c, P.dy_bf16);
             *reinterpret_cast<float4*>(Bs + (size_t)bp * WG_LD + pc * 4) = v;
         }
         __syncthreads();
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad16_kernel(const WgradArgs 
             const int gy = my0 * P.sb + yy, gx = mx0 * P.sb + xx;
             const int c = co0 + pc * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < P.Hy && gx < P.Wy && c < P.Cout) v = *reinterpret_cast<const float4*>(P.dy + (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c);
+            if (gy < P.Hy && gx < P.Wy && c < P.Cout) v = load4_f32_or_bf16(P.dy, (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c, P.dy_bf16);
             bias4.x += v.x; bias4.y += v.y; bias4.z += v.z; bias4.w += v.w;
             *reinterpret_cast<uint2*>(Bs + (size_t)bp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
         }
