@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void sla_bwd_a16_kernel(SlaBwdArgs P) {
         for (int u = 0; u < 4; ++u) {
             const int p = t * 32 + rg + 8 * u;
             if (p < P.N) {
-                const float4 kv = *reinterpret_cast<const float4*>(P.k + base + (size_t)p * 256);
+                const float4 kv = load4_f32_or_bf16(P.k, base + (size_t)p * 256, P.io_bf16);
                 mx.x = fmaxf(mx.x, kv.x); mx.y = fmaxf(mx.y, kv.y); mx.z = fmaxf(mx.z, kv.z); mx.w = fmaxf(mx.w, kv.w);
             }
         }
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256) void sla_bwd_a16_kernel(SlaBwdArgs P) {
             const bool ok = p < P.N;
             if (ok) {
                 const size_t o = base + (size_t)p * 256;
-                kv = *reinterpret_cast<const float4*>(P.k + o); vv = *reinterpret_cast<const float4*>(P.v + o);
-                qv = *reinterpret_cast<const float4*>(P.q + o); dv = *reinterpret_cast<const float4*>(P.dOut + o);
+                kv = load4_f32_or_bf16(P.k, o, P.io_bf16); vv = load4_f32_or_bf16(P.v, o, P.io_bf16);
+                qv = load4_f32_or_bf16(P.q, o, P.io_bf16); dv = load4_f32_or_bf16(P.dOut, o, P.io_bf16);
                 kv.x = __builtin_amdgcn_exp2f((kv.x - km.x) * L2E); kv.y = __builtin_amdgcn_exp2f((kv.y - km.y) * L2E);
                 kv.z = __builtin_amdgcn_exp2f((kv.z - km.z) * L2E); kv.w = __builtin_amdgcn_exp2f((kv.w - km.w) * L2E);
                 ks4.x += kv.x; ks4.y += kv.y; ks4.z += kv.z; ks4.w += kv.w;
@@ -529,10 +529,10 @@ __global__ __launch_bounds__(256) void sla_bwd_b16_kernel(SlaBwdArgs P) {
             const bool ok = p < P.N;
             const size_t o = ((size_t)n * P.N + (ok ? p : 0)) * 256 + h * 32 + 4 * q;
             const size_t go = ((size_t)n * P.N + (ok ? p : 0)) * P.dstride + h * 32 + 4 * q;
-            float4 q0 = *reinterpret_cast<const float4*>(P.q + o), q1 = *reinterpret_cast<const float4*>(P.q + o + 16);
-            float4 k0 = *reinterpret_cast<const float4*>(P.k + o), k1 = *reinterpret_cast<const float4*>(P.k + o + 16);
-            const float4 v0 = *reinterpret_cast<const float4*>(P.v + o), v1 = *reinterpret_cast<const float4*>(P.v + o + 16);
-            const float4 d0 = *reinterpret_cast<const float4*>(P.dOut + o), d1 = *reinterpret_cast<const float4*>(P.dOut + o + 16);
+            float4 q0 = load4_f32_or_bf16(P.q, o, P.io_bf16), q1 = load4_f32_or_bf16(P.q, o + 16, P.io_bf16);
+            float4 k0 = load4_f32_or_bf16(P.k, o, P.io_bf16), k1 = load4_f32_or_bf16(P.k, o + 16, P.io_bf16);
+            const float4 v0 = load4_f32_or_bf16(P.v, o, P.io_bf16), v1 = load4_f32_or_bf16(P.v, o + 16, P.io_bf16);
+            const float4 d0 = load4_f32_or_bf16(P.dOut, o, P.io_bf16), d1 = load4_f32_or_bf16(P.dOut, o + 16, P.io_bf16);
             // softmax over the 32 channels of this pixel (8 in-lane, 4 lanes)
             const float mx = max_q(fmaxf(fmaxf(fmaxf(q0.x, q0.y), fmaxf(q0.z, q0.w)), fmaxf(fmaxf(q1.x, q1.y), fmaxf(q1.z, q1.w))));
             q0.x = __builtin_amdgcn_exp2f((q0.x - mx) * L2E); q0.y = __builtin_amdgcn_exp2f((q0.y - mx) * L2E);
@@ -559,14 +559,15 @@ __global__ __launch_bounds__(256) void sla_bwd_b16_kernel(SlaBwdArgs P) {
                       + q1.x * dqsT[1][0] + q1.y * dqsT[1][1] + q1.z * dqsT[1][2] + q1.w * dqsT[1][3];
             dot = reduce_q(dot);
             if (ok) {
-                *reinterpret_cast<float4*>(P.O + o) = make_float4(oT[0][0], oT[0][1], oT[0][2], oT[0][3]);
-                *reinterpret_cast<float4*>(P.O + o + 16) = make_float4(oT[1][0], oT[1][1], oT[1][2], oT[1][3]);
-                *reinterpret_cast<float4*>(P.dv + go) = make_float4(dvT[0][0], dvT[0][1], dvT[0][2], dvT[0][3]);
-                *reinterpret_cast<float4*>(P.dv + go + 16) = make_float4(dvT[1][0], dvT[1][1], dvT[1][2], dvT[1][3]);
-                *reinterpret_cast<float4*>(P.dq + go) = make_float4(q0.x * (dqsT[0][0] - dot), q0.y * (dqsT[0][1] - dot), q0.z * (dqsT[0][2] - dot), q0.w * (dqsT[0][3] - dot));
-                *reinterpret_cast<float4*>(P.dq + go + 16) = make_float4(q1.x * (dqsT[1][0] - dot), q1.y * (dqsT[1][1] - dot), q1.z * (dqsT[1][2] - dot), q1.w * (dqsT[1][3] - dot));
-                *reinterpret_cast<float4*>(P.dk + go) = make_float4(k0.x * (dksT[0][0] - T0.x), k0.y * (dksT[0][1] - T0.y), k0.z * (dksT[0][2] - T0.z), k0.w * (dksT[0][3] - T0.w));
-                *reinterpret_cast<float4*>(P.dk + go + 16) = make_float4(k1.x * (dksT[1][0] - T1.x), k1.y * (dksT[1][1] - T1.y), k1.z * (dksT[1][2] - T1.z), k1.w * (dksT[1][3] - T1.w));
+                const int h16 = P.io_bf16;
+                store4_f32_or_bf16(P.O, o, make_float4(oT[0][0], oT[0][1], oT[0][2], oT[0][3]), h16);
+                store4_f32_or_bf16(P.O, o + 16, make_float4(oT[1][0], oT[1][1], oT[1][2], oT[1][3]), h16);
+                store4_f32_or_bf16(P.dv, go, make_float4(dvT[0][0], dvT[0][1], dvT[0][2], dvT[0][3]), h16);
+                store4_f32_or_bf16(P.dv, go + 16, make_float4(dvT[1][0], dvT[1][1], dvT[1][2], dvT[1][3]), h16);
+                store4_f32_or_bf16(P.dq, go, make_float4(q0.x * (dqsT[0][0] - dot), q0.y * (dqsT[0][1] - dot), q0.z * (dqsT[0][2] - dot), q0.w * (dqsT[0][3] - dot)), h16);
+                store4_f32_or_bf16(P.dq, go + 16, make_float4(q1.x * (dqsT[1][0] - dot), q1.y * (dqsT[1][1] - dot), q1.z * (dqsT[1][2] - dot), q1.w * (dqsT[1][3] - dot)), h16);
+                store4_f32_or_bf16(P.dk, go, make_float4(k0.x * (dksT[0][0] - T0.x), k0.y * (dksT[0][1] - T0.y), k0.z * (dksT[0][2] - T0.z), k0.w * (dksT[0][3] - T0.w)), h16);
+                store4_f32_or_bf16(P.dk, go + 16, make_float4(k1.x * (dksT[1][0] - T1.x), k1.y * (dksT[1][1] - T1.y), k1.z * (dksT[1][2] - T1.z), k1.w * (dksT[1][3] - T1.w)), h16);
             }
         }
     }

@@ -173,19 +173,22 @@ void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, fl
     const long npix = b.pix(lvl) * b.B;
     float* q = b.S; float* k = q + npix * HD; float* v = k + npix * HD; float* dOut = v + npix * HD; float* O = dOut + npix * HD;
     float* dq = O + npix * HD;      // [npix][dq | dk | dv]
-    proj(b, x, C, b.pk + sp.pk[0], nullptr, HD, lvl, nullptr, q);
-    proj(b, x, C, b.pk + sp.pk[1], nullptr, HD, lvl, nullptr, k);
-    proj(b, x, C, b.pk + sp.pk[2], nullptr, HD, lvl, nullptr, v);
-    proj(b, g, C, b.pt + sp.pt_o, nullptr, HD, lvl, nullptr, dOut);
+    const int io16 = (m->mode == MODE_BF16) ? 1 : 0;      // bf16 mode: q, k, v, dOut, O and dq|dk|dv are bf16 tensors in fp32-sized scratch places
+    proj(b, x, C, b.pk + sp.pk[0], nullptr, HD, lvl, nullptr, q, 0, io16);
+    proj(b, x, C, b.pk + sp.pk[1], nullptr, HD, lvl, nullptr, k, 0, io16);
+    proj(b, x, C, b.pk + sp.pk[2], nullptr, HD, lvl, nullptr, v, 0, io16);
+    proj(b, g, C, b.pt + sp.pt_o, nullptr, HD, lvl, nullptr, dOut, 0, io16);
     SlaBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.q = q; a.k = k; a.v = v; a.dOut = dOut; a.O = O; a.dq = dq; a.dk = dq + HD; a.dv = dq + 2 * HD; a.dstride = 3 * HD; a.A = b.sla_a;
+    a.q = q; a.k = k; a.v = v; a.dOut = dOut; a.O = O; a.dq = dq; a.dstride = 3 * HD; a.io_bf16 = io16; a.A = b.sla_a;
+    if (io16) { a.dk = reinterpret_cast<float*>(reinterpret_cast<char*>(dq) + HD * 2); a.dv = reinterpret_cast<float*>(reinterpret_cast<char*>(dq) + 2 * HD * 2); }
+    else { a.dk = dq + HD; a.dv = dq + 2 * HD; }
     a.NF = b.B * m->cfg.num_frames; a.N = b.size(lvl) * b.size(lvl); a.heads = m->cfg.attn_heads;
     a.bf16_mma = (m->mode == MODE_BF16);
     b.ok(launch_sla_bwd(a, b.st));
-    wgrad1x1(b, O, HD, g, C, sp.o_w, -1, lvl);
-    wgrad1x1_qkv(b, x, C, dq, HD, sp.w, nullptr, lvl);
-    proj(b, dq, 3 * HD, b.pt + sp.pt_qkv, nullptr, C, lvl, g, out);
+    wgrad1x1(b, O, HD, g, C, sp.o_w, -1, lvl, io16);
+    wgrad1x1_qkv(b, x, C, dq, HD, sp.w, nullptr, lvl, io16);
+    proj(b, dq, 3 * HD, b.pt + sp.pt_qkv, nullptr, C, lvl, g, out, io16, 0);
 }
 
 float* other(const LevelBufs& L, const float* cur) { return cur == L.ga ? L.gb : L.ga; }

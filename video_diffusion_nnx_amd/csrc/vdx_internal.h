@@ -168,7 +168,8 @@ hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st);
 struct SlaBwdArgs {
     const float* q; const float* k; const float* v; const float* dOut; float* O; float* dq; float* dk; float* dv; float* A;
     int NF, N, heads;
-    int dstride;                                  // row stride (floats) of dq / dk / dv: 256, or 768 for one interleaved buffer
+    int dstride;                                  // row stride (elements) of dq / dk / dv: 256, or 768 for one interleaved buffer
+    int io_bf16;                                  // q, k, v, dOut, O, dq, dk, dv are bf16 tensors (bf16 MFMA forms only)
     int bf16_mma;                                 // pass A on bf16 MFMA (bf16 mode) instead of the exact fp32 VALU form
 };
 size_t sla_bwd_scratch_floats(int NF, int heads);
