@@ -133,6 +133,7 @@ struct WgradArgs {
     // completed by the launcher
     int taps, sa, sb, ext, halo, Hm, Wm, Hy, Wy, PH, PW, co_tiles;
     unsigned m_iw, m_bw;                                   // magic multipliers (div_magic) of the staged window widths
+    int pwl;                                               // log2(PW) (bf16 form)
 };
 hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st);
 struct PackJob;

@@ -11,6 +11,7 @@
 // added to the fp32 gradient buffer with float atomics (dW is tiny next to the activations).
 #include "vdx_common.h"
 #include "vdx_internal.h"
+#include <stdlib.h>
 
 namespace vdx {
 
@@ -301,11 +302,11 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad16_kernel(const WgradArgs 
             *reinterpret_cast<uint2*>(Bs + (size_t)bp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
         }
         __syncthreads();
-        // ---- K loop: 32 patch positions per MFMA (PW == 8: one 8-position patch row per lane group) ----
+        // ---- K loop: 32 patch positions per MFMA (a lane group's 8 positions are consecutive in one patch row) ----
         const int npos = P.PH * P.PW;
         for (int k0 = 0; k0 < npos; k0 += 32) {
             const int p0 = k0 + 8 * q + qr, p1 = p0 + 4;
-            const int py0 = p0 >> 3, px0 = p0 & 7, py1 = p1 >> 3, px1 = p1 & 7;
+            const int py0 = p0 >> P.pwl, px0 = p0 & (P.PW - 1), py1 = p1 >> P.pwl, px1 = p1 & (P.PW - 1);   // PW = 8 or 16
             const char* a0 = As + (size_t)((py0 * P.sa) * IW + px0 * P.sa) * WG_RSB + wi * 64 + pcz * 8;
             const char* a1 = As + (size_t)((py1 * P.sa) * IW + px1 * P.sa) * WG_RSB + wi * 64 + pcz * 8;
             const char* b0 = Bs + (size_t)((py0 * P.sb) * BW + px0 * P.sb) * WG_RSB + wo * 64 + pcz * 8;
@@ -403,6 +404,8 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
     } else {
         a.sa = 1; a.sb = 2; a.ext = 3; a.halo = 1; a.Hm = a.H; a.Wm = a.W; a.Hy = 2 * a.H; a.Wy = 2 * a.W; a.PH = 4; a.PW = 8;
     }
+    static const int wide_patch = getenv("VDX_WGRAD_PW16") ? atoi(getenv("VDX_WGRAD_PW16")) : 1;
+    if (a.bf16_mma && a.kind == 0 && a.stride == 1 && a.kh == 3 && wide_patch && a.W >= 16) { a.PH = 8; a.PW = 16; }   // bf16 form: 128 positions per patch
     const int NT = a.taps <= 9 ? (a.taps == 1 ? 1 : 9) : 8;
     const int tap_groups = (a.taps + NT - 1) / NT;
     a.co_tiles = (a.Cout + 63) / 64;
@@ -413,7 +416,8 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
     const long tiles = (long)ci_tiles * a.co_tiles * tap_groups;
     long chunks = std::max<long>(1, std::min<long>(patches, 1024 / std::max<long>(1, tiles)));
     dim3 grid((unsigned)chunks, ci_tiles, a.co_tiles * tap_groups);
-    if (a.bf16_mma && a.PW == 8) {
+    if (a.bf16_mma && (a.PW == 8 || a.PW == 16)) {
+        a.pwl = a.PW == 8 ? 3 : 4;
         const size_t lds16 = ((size_t)IH * IW + (size_t)a.PH * a.sb * a.PW * a.sb) * WG_RSB + 4 * 64 * 4 + 32 * 4;
 #define VDX_WG16(NT_, NG_) do { auto kfn = conv_wgrad16_kernel<NT_, NG_>;                                                \
         if (lds16 > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16); if (e != hipSuccess) return e; } \
