@@ -83,6 +83,7 @@ __device__ __forceinline__ s16x4b pack4_bf16(const f32x4& v) {
     return __builtin_bit_cast(s16x4b, u);
 }
 
+template <bool IO16>
 __global__ __launch_bounds__(256) void attn_core_bwd16_kernel(AttnBwdArgs P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];      // [4 waves][4 images][16][AB_RS]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void attn_core_bwd16_kernel(AttnBwdArgs P) {
             const int c = (lq + 4 * u) * 4;
             uint2 pq = make_uint2(0u, 0u), pk = pq, pv = pq, pd = pq;
             if (rvalid) {
-                if (P.io_bf16) {
+                if (IO16) {
                     const char* src = reinterpret_cast<const char*>(P.qkv) + (grow * 3 * HD + h * 32 + c) * 2;
                     pq = *reinterpret_cast<const uint2*>(src);
                     pk = *reinterpret_cast<const uint2*>(src + HD * 2);
@@ -184,10 +185,10 @@ __global__ __launch_bounds__(256) void attn_core_bwd16_kernel(AttnBwdArgs P) {
             const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aq, bdSn, z, 0, 0, 0);
             if (ovalid) {
                 const size_t o_ = orow * HD + h * 32 + t * 16 + 4 * q, g_ = orow * P.dstride + h * 32 + t * 16 + 4 * q;
-                store4_f32_or_bf16(P.O, o_, make_float4(o[0], o[1], o[2], o[3]), P.io_bf16);
-                store4_f32_or_bf16(P.dv, g_, make_float4(dv[0], dv[1], dv[2], dv[3]), P.io_bf16);
-                store4_f32_or_bf16(P.dq, g_, make_float4(dq[0] * P.scale, dq[1] * P.scale, dq[2] * P.scale, dq[3] * P.scale), P.io_bf16);
-                store4_f32_or_bf16(P.dk, g_, make_float4(dk[0] * P.scale, dk[1] * P.scale, dk[2] * P.scale, dk[3] * P.scale), P.io_bf16);
+                store4_f32_or_bf16(P.O, o_, make_float4(o[0], o[1], o[2], o[3]), IO16);
+                store4_f32_or_bf16(P.dv, g_, make_float4(dv[0], dv[1], dv[2], dv[3]), IO16);
+                store4_f32_or_bf16(P.dq, g_, make_float4(dq[0] * P.scale, dq[1] * P.scale, dq[2] * P.scale, dq[3] * P.scale), IO16);
+                store4_f32_or_bf16(P.dk, g_, make_float4(dk[0] * P.scale, dk[1] * P.scale, dk[2] * P.scale, dk[3] * P.scale), IO16);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // images are rewritten for the next head
@@ -287,6 +288,7 @@ __device__ __forceinline__ float rowred_sum(float v) {
     v += dpp_row<0xB1>(v); v += dpp_row<0x4E>(v); return v + dpp_row<0x141>(v);
 }
 
+template <bool IO16>
 __global__ __launch_bounds__(256) void sla_bwd_a16_kernel(SlaBwdArgs P) {
     __shared__ __attribute__((aligned(16))) char imgs[4][4][32 * SA_RS];      // [wave][ks, v, qs, dOut]
     __shared__ float part[4][2][1024];                                        // per-wave ctx_un / dctx tiles
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256) void sla_bwd_a16_kernel(SlaBwdArgs P) {
         for (int u = 0; u < 4; ++u) {
             const int p = t * 32 + rg + 8 * u;
             if (p < P.N) {
-                const float4 kv = load4_f32_or_bf16(P.k, base + (size_t)p * 256, P.io_bf16);
+                const float4 kv = load4_f32_or_bf16(P.k, base + (size_t)p * 256, IO16);
                 mx.x = fmaxf(mx.x, kv.x); mx.y = fmaxf(mx.y, kv.y); mx.z = fmaxf(mx.z, kv.z); mx.w = fmaxf(mx.w, kv.w);
             }
         }
@@ -334,8 +336,8 @@ __global__ __launch_bounds__(256) void sla_bwd_a16_kernel(SlaBwdArgs P) {
             const bool ok = p < P.N;
             if (ok) {
                 const size_t o = base + (size_t)p * 256;
-                kv = load4_f32_or_bf16(P.k, o, P.io_bf16); vv = load4_f32_or_bf16(P.v, o, P.io_bf16);
-                qv = load4_f32_or_bf16(P.q, o, P.io_bf16); dv = load4_f32_or_bf16(P.dOut, o, P.io_bf16);
+                kv = load4_f32_or_bf16(P.k, o, IO16); vv = load4_f32_or_bf16(P.v, o, IO16);
+                qv = load4_f32_or_bf16(P.q, o, IO16); dv = load4_f32_or_bf16(P.dOut, o, IO16);
                 kv.x = __builtin_amdgcn_exp2f((kv.x - km.x) * L2E); kv.y = __builtin_amdgcn_exp2f((kv.y - km.y) * L2E);
                 kv.z = __builtin_amdgcn_exp2f((kv.z - km.z) * L2E); kv.w = __builtin_amdgcn_exp2f((kv.w - km.w) * L2E);
                 ks4.x += kv.x; ks4.y += kv.y; ks4.z += kv.z; ks4.w += kv.w;
@@ -488,6 +490,7 @@ __device__ __forceinline__ bf16x8 pack8_bf16(const float4& a, const float4& b) {
     return __builtin_bit_cast(bf16x8, u);
 }
 
+template <bool IO16>
 __global__ __launch_bounds__(256) void sla_bwd_b16_kernel(SlaBwdArgs P) {
     __shared__ float cm[32][33], dm[32][33];                 // ctx[d][e], dctx[d][e] of the current head
     __shared__ float km[32], ksu[32], Tv[32];
@@ -529,10 +532,10 @@ __global__ __launch_bounds__(256) void sla_bwd_b16_kernel(SlaBwdArgs P) {
             const bool ok = p < P.N;
             const size_t o = ((size_t)n * P.N + (ok ? p : 0)) * 256 + h * 32 + 4 * q;
             const size_t go = ((size_t)n * P.N + (ok ? p : 0)) * P.dstride + h * 32 + 4 * q;
-            float4 q0 = load4_f32_or_bf16(P.q, o, P.io_bf16), q1 = load4_f32_or_bf16(P.q, o + 16, P.io_bf16);
-            float4 k0 = load4_f32_or_bf16(P.k, o, P.io_bf16), k1 = load4_f32_or_bf16(P.k, o + 16, P.io_bf16);
-            const float4 v0 = load4_f32_or_bf16(P.v, o, P.io_bf16), v1 = load4_f32_or_bf16(P.v, o + 16, P.io_bf16);
-            const float4 d0 = load4_f32_or_bf16(P.dOut, o, P.io_bf16), d1 = load4_f32_or_bf16(P.dOut, o + 16, P.io_bf16);
+            float4 q0 = load4_f32_or_bf16(P.q, o, IO16), q1 = load4_f32_or_bf16(P.q, o + 16, IO16);
+            float4 k0 = load4_f32_or_bf16(P.k, o, IO16), k1 = load4_f32_or_bf16(P.k, o + 16, IO16);
+            const float4 v0 = load4_f32_or_bf16(P.v, o, IO16), v1 = load4_f32_or_bf16(P.v, o + 16, IO16);
+            const float4 d0 = load4_f32_or_bf16(P.dOut, o, IO16), d1 = load4_f32_or_bf16(P.dOut, o + 16, IO16);
             // softmax over the 32 channels of this pixel (8 in-lane, 4 lanes)
             const float mx = max_q(fmaxf(fmaxf(fmaxf(q0.x, q0.y), fmaxf(q0.z, q0.w)), fmaxf(fmaxf(q1.x, q1.y), fmaxf(q1.z, q1.w))));
             q0.x = __builtin_amdgcn_exp2f((q0.x - mx) * L2E); q0.y = __builtin_amdgcn_exp2f((q0.y - mx) * L2E);
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(256) void sla_bwd_b16_kernel(SlaBwdArgs P) {
                       + q1.x * dqsT[1][0] + q1.y * dqsT[1][1] + q1.z * dqsT[1][2] + q1.w * dqsT[1][3];
             dot = reduce_q(dot);
             if (ok) {
-                const int h16 = P.io_bf16;
+                const int h16 = IO16;
                 store4_f32_or_bf16(P.O, o, make_float4(oT[0][0], oT[0][1], oT[0][2], oT[0][3]), h16);
                 store4_f32_or_bf16(P.O, o + 16, make_float4(oT[1][0], oT[1][1], oT[1][2], oT[1][3]), h16);
                 store4_f32_or_bf16(P.dv, go, make_float4(dvT[0][0], dvT[0][1], dvT[0][2], dvT[0][3]), h16);
@@ -576,7 +579,8 @@ __global__ __launch_bounds__(256) void sla_bwd_b16_kernel(SlaBwdArgs P) {
 hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st) {
     if (a.bf16_mma && a.L <= 16) {
         const long blocks = (a.nseq + 3) / 4;
-        hipLaunchKernelGGL(attn_core_bwd16_kernel, dim3((unsigned)blocks), dim3(256), 4 * 4 * 16 * AB_RS, st, a);
+        if (a.io_bf16) hipLaunchKernelGGL(attn_core_bwd16_kernel<true>, dim3((unsigned)blocks), dim3(256), 4 * 4 * 16 * AB_RS, st, a);
+        else hipLaunchKernelGGL(attn_core_bwd16_kernel<false>, dim3((unsigned)blocks), dim3(256), 4 * 4 * 16 * AB_RS, st, a);
         return hipGetLastError();
     }
     const size_t lds = ((size_t)4 * a.L * 33 + 2 * a.L * (a.L + 1)) * 4;
@@ -592,12 +596,14 @@ hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st) {
 size_t sla_bwd_scratch_floats(int NF, int heads) { return (size_t)NF * heads * SLA_A; }
 
 hipError_t launch_sla_bwd(const SlaBwdArgs& a, hipStream_t st) {
-    if (a.bf16_mma) hipLaunchKernelGGL(sla_bwd_a16_kernel, dim3(a.NF, a.heads), dim3(256), 0, st, a);
+    if (a.bf16_mma && a.io_bf16) hipLaunchKernelGGL(sla_bwd_a16_kernel<true>, dim3(a.NF, a.heads), dim3(256), 0, st, a);
+    else if (a.bf16_mma) hipLaunchKernelGGL(sla_bwd_a16_kernel<false>, dim3(a.NF, a.heads), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(sla_bwd_a_kernel, dim3(a.NF, a.heads), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int tiles = (a.N + 255) / 256;
-    if (a.bf16_mma) hipLaunchKernelGGL(sla_bwd_b16_kernel, dim3(a.NF * tiles), dim3(256), 0, st, a);
+    if (a.bf16_mma && a.io_bf16) hipLaunchKernelGGL(sla_bwd_b16_kernel<true>, dim3(a.NF * tiles), dim3(256), 0, st, a);
+    else if (a.bf16_mma) hipLaunchKernelGGL(sla_bwd_b16_kernel<false>, dim3(a.NF * tiles), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(sla_bwd_b_kernel, dim3(a.NF * tiles), dim3(256), 0, st, a);
     return hipGetLastError();
 }
