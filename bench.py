@@ -115,7 +115,8 @@ def time_conv_kernels(unet, frames, size, batch, mode, act='f32', reps=5):
         sym = f'vdx::conv_igemm_kernel<{mode_id}, {64 if cout <= 64 else 128}, 2, {4 if narrow else 8}>'
         if (mode == 'bf16' and kind in ('c3', 'c3p') and cin == 64 and cout == 64 and s % 16 == 0
                 and batch * frames * (s // 16) ** 2 >= 1024):                            # launch_conv's persistent level-0 specialisation
-            sym = f'vdx::conv64p_kernel<{"true" if act == "bf16" else "false"}>'
+            b16 = 'true' if act == 'bf16' else 'false'                                    # template <IN16, PRO, OUT16>
+            sym = f'vdx::conv64p_kernel<{b16}, {"true" if kind == "c3p" else "false"}, {b16}>'
         if (mode == 'bf16' and act == 'bf16' and kind == 'c3' and cin == 128 and cout == 64 and s % 16 == 0
                 and batch * frames * (s // 16) ** 2 >= 1024):
             sym = 'vdx::conv128x64p_kernel'

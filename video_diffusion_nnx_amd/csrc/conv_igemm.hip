@@ -351,7 +351,8 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
 constexpr int C64_HALO = 18 * 18;
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + 16 * (chunk ^ (row & 7)); }
 
-template <bool IN16>
+// PRO / OUT16: prologue present, bf16 output -- compile-time, so the unused path costs no registers or issue slots
+template <bool IN16, bool PRO, bool OUT16>
 __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
     using M = Mma<MODE_BF16>;
     constexpr int PCH = IN16 ? 8 : 4;                 // channels per 16-byte global piece
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             const bool ok = (okmask >> u) & 1u;
             if (IN16) {
                 u32x4 v = sreg[u];
-                if (P.pro) {
+                if (PRO) {
                     const unsigned w4[4] = {v.x, v.y, v.z, v.w};
                     unsigned o4[4];
 #pragma unroll
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
                 *reinterpret_cast<u32x4*>(dst + ploff[u]) = v;
             } else {
                 float4 f = make_float4(__uint_as_float(sreg[u].x), __uint_as_float(sreg[u].y), __uint_as_float(sreg[u].z), __uint_as_float(sreg[u].w));
-                if (P.pro) {
+                if (PRO) {
                     const float4 a = *reinterpret_cast<const float4*>(coefA + pch[u]);
                     const float4 d = *reinterpret_cast<const float4*>(coefD + pch[u]);
                     f.x = ok ? silu_f(fmaf(f.x, a.x, d.x)) : 0.f; f.y = ok ? silu_f(fmaf(f.y, a.y, d.y)) : 0.f;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     };
     // GroupNorm-apply coefficients of sample b (all threads call; ends with a barrier)
     auto make_coef = [&](int b) {
-        if (!P.pro) return;
+        if (!PRO) return;
         if (tid < P.groups) {
             float m, rsd;
             gn_mean_rstd(P.in_stats, b, tid, P.groups, (double)P.F * P.H * P.W * (64 / P.groups), m, rsd);
@@ -548,7 +549,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm) {
                     const float4 v = make_float4(acc[tm][tn][0] + bias4[tm].x, acc[tm][tn][1] + bias4[tm].y, acc[tm][tn][2] + bias4[tm].z, acc[tm][tn][3] + bias4[tm].w);
-                    store4_f32_or_bf16(P.y, gout + tm * 16 + 4 * q, v, P.y_bf16);
+                    store4_f32_or_bf16(P.y, gout + tm * 16 + 4 * q, v, OUT16 ? 1 : 0);
                     ssum[tm][0] += v.x; ssum[tm][1] += v.y; ssum[tm][2] += v.z; ssum[tm][3] += v.w;
                     ssq[tm][0] += v.x * v.x; ssq[tm][1] += v.y * v.y; ssq[tm][2] += v.z * v.z; ssq[tm][3] += v.w * v.w;
                 }
@@ -575,7 +576,17 @@ static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(512), lds, st, a, tpb, total);
         return hipGetLastError();
     };
-    return a.x0_bf16 ? launch(conv64p_kernel<true>) : launch(conv64p_kernel<false>);
+    const int v = (a.x0_bf16 ? 4 : 0) | (a.pro ? 2 : 0) | (a.y_bf16 ? 1 : 0);
+    switch (v) {
+        case 0: return launch(conv64p_kernel<false, false, false>);
+        case 1: return launch(conv64p_kernel<false, false, true>);
+        case 2: return launch(conv64p_kernel<false, true, false>);
+        case 3: return launch(conv64p_kernel<false, true, true>);
+        case 4: return launch(conv64p_kernel<true, false, false>);
+        case 5: return launch(conv64p_kernel<true, false, true>);
+        case 6: return launch(conv64p_kernel<true, true, false>);
+        default: return launch(conv64p_kernel<true, true, true>);
+    }
 }
 
 // ---- persistent 3x3 conv with Cin = 128 (two-pointer concat of 64 + 64, or one 128-channel tensor), Cout = 64, bf16 inputs ----

@@ -581,7 +581,7 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
     }
 
     T t;
-    t.fetch(P.x, xbase, P.io_bf16, chunk * R, P.N, P.C, tid);
+    t.fetch(P.x, xbase, IO16 ? 1 : P.io_bf16, chunk * R, P.N, P.C, tid);
     t.put(smem, tid);
     __syncthreads();
     for (int sub = 0; sub < P.nsub; ++sub) {
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
         if (r0 >= P.N) break;
         const char* xs = smem + (sub & 1) * T::BUF;
         const bool more = (sub + 1 < P.nsub) && (r0 + 64 < P.N);
-        if (more) t.fetch(P.x, xbase, P.io_bf16, r0 + 64, P.N, P.C, tid);
+        if (more) t.fetch(P.x, xbase, IO16 ? 1 : P.io_bf16, r0 + 64, P.N, P.C, tid);
         // q[d, n] of this head: lane (lp, q) = (pixel lp, channels 4q+r)
         f32x4 acc[2][4];
 #pragma unroll
@@ -665,9 +665,9 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
             for (int tn = 0; tn < TNO; ++tn) {
                 const int row = r0 + (tn0 + tn) * 16 + lp;
                 if (row >= P.N) continue;
-                const float4 xr = load4_f32_or_bf16(P.x, xbase + (size_t)row * P.C + co, P.io_bf16);
+                const float4 xr = load4_f32_or_bf16(P.x, xbase + (size_t)row * P.C + co, IO16 ? 1 : P.io_bf16);
                 store4_f32_or_bf16(P.y, xbase + (size_t)row * P.C + co,
-                                   make_float4(oacc[tmo][tn][0] + xr.x, oacc[tmo][tn][1] + xr.y, oacc[tmo][tn][2] + xr.z, oacc[tmo][tn][3] + xr.w), P.io_bf16);
+                                   make_float4(oacc[tmo][tn][0] + xr.x, oacc[tmo][tn][1] + xr.y, oacc[tmo][tn][2] + xr.z, oacc[tmo][tn][3] + xr.w), IO16 ? 1 : P.io_bf16);
             }
         }
         if (more) t.put(smem + ((sub + 1) & 1) * T::BUF, tid);
