@@ -335,10 +335,19 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
     for (long pix = (long)blockIdx.x * ppb + pl; pix < npix; pix += (long)gridDim.x * ppb) {
         for (int co = 0; co < Cout; ++co) {
             float s = 0.f;
-            for (int c = sub * 4; c < D; c += lpp * 4) {
-                const float4 v = load4_f32_or_bf16(x, (size_t)pix * D + c, x_bf16);
-                s += v.x * w[(size_t)c * Cout + co] + v.y * w[(size_t)(c + 1) * Cout + co]
-                   + v.z * w[(size_t)(c + 2) * Cout + co] + v.w * w[(size_t)(c + 3) * Cout + co];
+            if (x_bf16) {                                 // bf16 activation storage: 8 channels = 16 bytes per lane
+                for (int c = sub * 8; c < D; c += lpp * 8) {
+                    float v[8];
+                    unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + ((size_t)pix * D + c) * 2), v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s = fmaf(v[k], w[(size_t)(c + k) * Cout + co], s);
+                }
+            } else {
+                for (int c = sub * 4; c < D; c += lpp * 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(x + (size_t)pix * D + c);
+                    s += v.x * w[(size_t)c * Cout + co] + v.y * w[(size_t)(c + 1) * Cout + co]
+                       + v.z * w[(size_t)(c + 2) * Cout + co] + v.w * w[(size_t)(c + 3) * Cout + co];
+                }
             }
             for (int o = 1; o < lpp; o <<= 1) s += __shfl_xor(s, o);
             if (sub == 0) y[(size_t)pix * Cout + co] = s + bias[co];
@@ -347,8 +356,11 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
 }
 
 hipError_t launch_final_conv(const float* x, const float* w, const float* bias, float* y, long npix, int D, int Cout, int x_bf16, hipStream_t st) {
+    const int per = (x_bf16 && D % 8 == 0) ? 8 : 4;       // channels per lane and pass
+    if (per == 4) x_bf16 = x_bf16 ? -1 : 0;
+    if (x_bf16 < 0) return hipErrorInvalidValue;          // bf16 tensors have D % 8 == 0 (config check)
     int lpp = 1;
-    while (lpp * 4 < D && lpp < 16) lpp <<= 1;
+    while (lpp * per < D && lpp < 16) lpp <<= 1;
     const int ppb = 256 / lpp;
     const int blocks = (int)std::min<long>((npix + ppb - 1) / ppb, 4096);
     hipLaunchKernelGGL(final_conv_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, Cout, lpp, x_bf16);
