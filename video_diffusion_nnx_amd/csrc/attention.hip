@@ -625,6 +625,111 @@ static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---- wide levels (C >= 256): one workgroup per (head, sequence chunk) ----------------------------------------------------------------
+// The per-head q/k/v weights (96 rows x C bf16, up to 99 KB) are loaded into LDS ONCE per workgroup instead of once per 64 rows;
+// every wave then walks its own sequences with no workgroup barrier: x fragments (16 tokens x 32 channels) come straight from
+// global memory / L2 (each x row is read by the 8 head-workgroups), weight fragments from LDS, and the core runs in registers as in
+// attention_reg_kernel.  Output: O[row][head*32 + d] bf16; the out-projection (+bias, +residual) is a plain 1x1 conv_igemm.
+template <bool IO16>
+__global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, const int seq_per_block) {
+    using M = Mma<MODE_BF16>;
+    constexpr int D = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // W_h [96 rows][C * 2 + 32]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    const int h = blockIdx.x, HD = P.heads * D;
+    const int RSW = P.C * 2 + 32;                                     // +32: conflict-free ds_read_b128 over 16 rows
+    const int cpr = P.C / 8;                                          // 16-byte pieces per weight row
+    for (int i = tid; i < 96 * cpr; i += 512) {
+        const int row = i / cpr, pc = i - row * cpr;
+        const int part = row >> 5, rr = row & 31;
+        *reinterpret_cast<uint4*>(smem + row * RSW + pc * 16) = *reinterpret_cast<const uint4*>(
+            reinterpret_cast<const char*>(P.wqkv) + ((size_t)(part * HD + h * D + rr) * P.CPad) * 2 + pc * 16);
+    }
+    f32x4 bq[2], bk[2], bv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float4 a = *reinterpret_cast<const float4*>(P.bqkv + h * D + t * 16 + 4 * q);
+        const float4 b = *reinterpret_cast<const float4*>(P.bqkv + HD + h * D + t * 16 + 4 * q);
+        const float c = P.bqkv[2 * HD + h * D + t * 16 + lp];
+        bq[t] = f32x4{a.x, a.y, a.z, a.w}; bk[t] = f32x4{b.x, b.y, b.z, b.w}; bv[t] = f32x4{c, c, c, c};
+    }
+    const float escale = P.scale * 1.44269504088896f;
+    const bool masked = P.L < 16;
+    __syncthreads();
+    const long s0 = (long)blockIdx.y * seq_per_block;
+    const int nkt = P.C / 32;
+    const char* wrow = smem + lp * RSW + q * 16;
+    for (long s = s0 + w; s < s0 + seq_per_block && s < P.nseq; s += 8) {
+        const long ro = (s / P.inner) * P.outer_stride + (s % P.inner) * P.inner_stride + (long)lp * P.tok_stride;   // token lp of sequence s
+        const bool tv = lp < P.L;
+        f32x4 aq[2], ak[2], av[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { aq[t] = bq[t]; ak[t] = bk[t]; av[t] = bv[t]; }
+        for (int kt = 0; kt < nkt; ++kt) {
+            uint4 xf = make_uint4(0, 0, 0, 0);
+            if (tv) {
+                if (IO16) xf = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.x) + (size_t)(ro + kt * 32 + 8 * q) * 2);
+                else {
+                    const float4 a = *reinterpret_cast<const float4*>(P.x + ro + kt * 32 + 8 * q), b = *reinterpret_cast<const float4*>(P.x + ro + kt * 32 + 8 * q + 4);
+                    xf = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint4 wq = *reinterpret_cast<const uint4*>(wrow + (0 * 32 + t * 16) * RSW + kt * 64);
+                const uint4 wk = *reinterpret_cast<const uint4*>(wrow + (1 * 32 + t * 16) * RSW + kt * 64);
+                const uint4 wv = *reinterpret_cast<const uint4*>(wrow + (2 * 32 + t * 16) * RSW + kt * 64);
+                M::mma(aq[t], wq, xf);
+                M::mma(ak[t], wk, xf);
+                M::mma(av[t], xf, wv);                        // swapped: rows = tokens, cols = d
+            }
+        }
+        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};                 // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
+        M::mma16(sc, ak[0], aq[0]);
+        M::mma16(sc, ak[1], aq[1]);
+        if (masked) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (4 * q + r >= P.L) sc[r] = -1e30f;
+        }
+        const float mx = max_q(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[r] = __builtin_amdgcn_exp2f((sc[r] - mx) * escale); sum += sc[r]; }
+        const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sc[r] *= inv;
+        const size_t orow = (size_t)(ro / P.C) * HD + h * D;          // strides are multiples of C: ro / C = row index
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            M::mma16(o, av[t], sc);
+            if (tv) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.oscratch) + (orow + t * 16 + 4 * q) * 2) =
+                        make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        }
+    }
+}
+
+hipError_t launch_attention_heads(AttnArgs a, hipStream_t st) {
+    a.CPad = conv_cin_pad(MODE_BF16, a.C);
+    if (a.heads != 8 || a.L > 16 || a.C % 32 || !a.oscratch) return hipErrorInvalidValue;
+    const size_t lds = (size_t)96 * (a.C * 2 + 32);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    // enough workgroups per head to fill the chip twice, at least 16 sequences (2 per wave) each
+    long spb = std::max<long>(16, (a.nseq * a.heads + 511) / 512);
+    spb = (spb + 7) / 8 * 8;
+    const long chunks = (a.nseq + spb - 1) / spb;
+    auto go = [&](auto kfn) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kfn, dim3(a.heads, (unsigned)chunks), dim3(512), lds, st, a, (int)spb);
+        return hipGetLastError();
+    };
+    return a.io_bf16 ? go(attention_head_kernel<true>) : go(attention_head_kernel<false>);
+}
+
 template <int MODE, int TMA>
 static hipError_t launch_attn_reg_t(const AttnArgs& a, hipStream_t st) {
     const size_t lds = 512 + (size_t)(64 + 96) * ROW_STRIDE + (size_t)TMA * 16 * (32 * Mma<MODE>::ES + 16);

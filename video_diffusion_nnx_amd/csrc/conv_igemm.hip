@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
             v.z = acc[tm][tn][2] + bias.z; v.w = acc[tm][tn][3] + bias.w;
             if (cvalid && gout[tn] >= 0) {
                 if (P.res) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(P.res + (size_t)gout[tn] * P.Cout + co);
+                    const float4 r4 = load4_f32_or_bf16(P.res, (size_t)gout[tn] * P.Cout + co, P.res_bf16);
                     v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                 }
                 if (P.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.y) + ((size_t)gout[tn] * P.Cout + co) * 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));

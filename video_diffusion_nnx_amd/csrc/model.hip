@@ -12,6 +12,7 @@
 #include "vdx_common.h"
 #include "vdx_internal.h"
 #include "model.h"
+#include <stdlib.h>
 
 namespace vdx {
 
@@ -252,11 +253,14 @@ int model_build(Model* m) {
     res_slots(m, m->fin, pixels(0));
     // SLA scratch: sized for the largest level
     m->sla_ws_bytes_per_sample = 0;
-    if (c.use_sparse_linear_attn)
-        for (int l = 0; l < nl; ++l) {
-            const long s = c.image_size >> l;
+    for (int l = 0; l < nl; ++l) {
+        const long s = c.image_size >> l;
+        if (c.use_sparse_linear_attn)
             m->sla_ws_bytes_per_sample = std::max(m->sla_ws_bytes_per_sample, sla_workspace_bytes(m->mode, (int)F, (int)(s * s), H));
-        }
+        // the same scratch holds the per-head attention output [F * s * s rows][heads * 32] bf16 of launch_attention_heads (wide levels)
+        if (c.dim * c.dim_mults[l] >= 256)
+            m->sla_ws_bytes_per_sample = std::max(m->sla_ws_bytes_per_sample, (size_t)F * s * s * c.attn_heads * 32 * 2);
+    }
     return VDX_OK;
 }
 
@@ -395,6 +399,21 @@ static hipError_t run_attn(const Fwd& f, const AttnP& ap, const float* x, float*
     if (temporal) { a.L = (int)Fr; a.nseq = f.B * hw; a.inner = hw; a.inner_stride = ap.C; a.outer_stride = Fr * hw * ap.C; a.tok_stride = hw * ap.C; }
     else { a.L = (int)hw; a.nseq = f.B * Fr; a.inner = 1; a.inner_stride = 0; a.outer_stride = hw * ap.C; a.tok_stride = ap.C; }
     a.io_bf16 = f.a16;
+    // wide levels in bf16 mode: per-head kernel (weights resident in LDS) + the out-projection as a 1x1 conv; VDX_ATTN_HEADS=0 disables
+    static const int use_heads = getenv("VDX_ATTN_HEADS") ? atoi(getenv("VDX_ATTN_HEADS")) : 1;
+    if (use_heads && m->mode == MODE_BF16 && temporal && a.L <= 16 && a.heads == 8 && ap.C >= 256 && ap.C % 32 == 0 &&
+        (size_t)96 * (ap.C * 2 + 32) <= 160 * 1024 && (size_t)Fr * S * S * a.heads * 64 <= m->sla_ws_bytes_per_sample) {
+        a.oscratch = f.sla_ws;
+        hipError_t e = launch_attention_heads(a, f.st);
+        if (e != hipSuccess) return e;
+        ConvArgs c;
+        memset(&c, 0, sizeof(c));
+        c.x0 = reinterpret_cast<const float*>(f.sla_ws); c.C0 = a.heads * 32; c.x0_bf16 = 1;
+        c.wp = f.pk + ap.pk_o; c.bias = f.p + ap.o_b; c.y = y; c.Cout = ap.C; c.y_bf16 = f.a16;
+        c.res = x; c.res_bf16 = f.a16;
+        c.NF = f.B * (int)Fr; c.F = (int)Fr; c.H = (int)S; c.W = (int)S; c.kind = 0; c.kh = c.kw = 1; c.stride = 1; c.pad = 0;
+        return launch_conv(m->mode, c, f.st);
+    }
     return launch_attention(m->mode, a, f.st);
 }
 

@@ -30,6 +30,7 @@ struct ConvArgs {
     int x0_bf16, y_bf16;            // x0 / y are stored as bf16 (the intra-ResnetBlock tensors in bf16 mode); y_bf16 excludes res
     int x1_bf16;                    // x1 stored as bf16 (bf16 activation storage)
     const float* res;               // optional residual added to the output: y = conv + bias + res  ([.., Cout] like y)
+    int res_bf16;                   // res stored as bf16
     int wrows, wrow0;               // packed weight rows per tap / first row (0,0 = Cout rows from 0): slices a wider packing
     // completed by launch_conv
     int Ho, Wo, Hy, Wy, CinPad, PH, PW, NP, tiles_y, tiles_x;
@@ -78,9 +79,13 @@ struct AttnArgs {
     long nseq, inner, inner_stride, outer_stride, tok_stride;
     float scale;
     int io_bf16;                              // x and y stored as bf16 (bf16 activation storage); strides stay in elements
+    void* oscratch;                           // [rows][heads*32] bf16: per-head attention output of launch_attention_heads
     int CPad, HDPad;                          // completed by the launcher
 };
 hipError_t launch_attention(int mode, AttnArgs a, hipStream_t st);
+// bf16 mode, <= 16 tokens, 8 heads: q/k/v projection + attention core per head (one workgroup per head: its weights resident in LDS,
+// every wave streams its own sequences, no barriers) -> a.oscratch; the out-projection + residual is a 1x1 conv_igemm by the caller
+hipError_t launch_attention_heads(AttnArgs a, hipStream_t st);
 
 // y = SpatialLinearAttention(x) + x, x/y channel-last [NF][N][C]; 8 heads x 32
 struct SlaArgs {
