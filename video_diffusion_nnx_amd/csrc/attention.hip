@@ -630,8 +630,11 @@ static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
 // every wave then walks its own sequences with no workgroup barrier: x fragments (16 tokens x 32 channels) come straight from
 // global memory / L2 (each x row is read by the 8 head-workgroups), weight fragments from LDS, and the core runs in registers as in
 // attention_reg_kernel.  Output: O[row][head*32 + d] bf16; the out-projection (+bias, +residual) is a plain 1x1 conv_igemm.
-template <bool IO16>
+template <bool IO16, int TT>
 __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, const int seq_per_block) {
+    // TT sequences per wave at a time: each weight fragment read from LDS feeds TT MFMAs (one sequence per read would make the kernel
+    // LDS-bandwidth bound: 6 KB of fragments per 6 MFMAs per wave), and the x fragments run through a 4-deep register ring so that
+    // global loads are issued four K steps ahead of their use.
     using M = Mma<MODE_BF16>;
     constexpr int D = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // W_h [96 rows][C * 2 + 32]
@@ -657,67 +660,111 @@ __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, c
     const float escale = P.scale * 1.44269504088896f;
     const bool masked = P.L < 16;
     __syncthreads();
-    const long s0 = (long)blockIdx.y * seq_per_block;
-    const int nkt = P.C / 32;
+    const int s0 = blockIdx.y * seq_per_block;
+    const int send = min((int)P.nseq, s0 + seq_per_block);
+    const int nkt = P.C / 32;                                         // multiple of 4 (launcher)
     const char* wrow = smem + lp * RSW + q * 16;
-    for (long s = s0 + w; s < s0 + seq_per_block && s < P.nseq; s += 8) {
-        const long ro = (s / P.inner) * P.outer_stride + (s % P.inner) * P.inner_stride + (long)lp * P.tok_stride;   // token lp of sequence s
-        const bool tv = lp < P.L;
-        f32x4 aq[2], ak[2], av[2];
+    const bool tv = lp < P.L;
+    const int inner = (int)P.inner;
+
+    // fetch side: group of TT sequences starting at fs, K step fk
+    int fs = s0 + w * TT, fk = 0;
+    long fro[TT];
+    auto set_group = [&]() {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { aq[t] = bq[t]; ak[t] = bk[t]; av[t] = bv[t]; }
-        for (int kt = 0; kt < nkt; ++kt) {
-            uint4 xf = make_uint4(0, 0, 0, 0);
-            if (tv) {
-                if (IO16) xf = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.x) + (size_t)(ro + kt * 32 + 8 * q) * 2);
+        for (int tt = 0; tt < TT; ++tt) {
+            const int sq = fs + tt;
+            fro[tt] = -1;
+            if (tv && sq < send) fro[tt] = (long)(sq / inner) * P.outer_stride + (long)(sq % inner) * P.inner_stride + (long)lp * P.tok_stride + 8 * q;
+        }
+    };
+    auto fetch = [&](uint4 (&dst)[TT]) {
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            dst[tt] = make_uint4(0, 0, 0, 0);
+            if (fro[tt] >= 0) {
+                const size_t e = (size_t)fro[tt] + fk * 32;
+                if (IO16) dst[tt] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.x) + e * 2);
                 else {
-                    const float4 a = *reinterpret_cast<const float4*>(P.x + ro + kt * 32 + 8 * q), b = *reinterpret_cast<const float4*>(P.x + ro + kt * 32 + 8 * q + 4);
-                    xf = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+                    const float4 a = *reinterpret_cast<const float4*>(P.x + e), b = *reinterpret_cast<const float4*>(P.x + e + 4);
+                    dst[tt] = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
                 }
             }
+        }
+        if (++fk == nkt) { fk = 0; fs += 8 * TT; set_group(); }
+    };
+    uint4 ring[4][TT];
+    set_group();
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const uint4 wq = *reinterpret_cast<const uint4*>(wrow + (0 * 32 + t * 16) * RSW + kt * 64);
-                const uint4 wk = *reinterpret_cast<const uint4*>(wrow + (1 * 32 + t * 16) * RSW + kt * 64);
-                const uint4 wv = *reinterpret_cast<const uint4*>(wrow + (2 * 32 + t * 16) * RSW + kt * 64);
-                M::mma(aq[t], wq, xf);
-                M::mma(ak[t], wk, xf);
-                M::mma(av[t], xf, wv);                        // swapped: rows = tokens, cols = d
+    for (int u = 0; u < 4; ++u) fetch(ring[u]);
+
+    for (int cs = s0 + w * TT; cs < send; cs += 8 * TT) {
+        long crow[TT];                                                // row index (x element offset / C) of token lp, or -1
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            const int sq = cs + tt;
+            crow[tt] = -1;
+            if (tv && sq < send) crow[tt] = ((long)(sq / inner) * P.outer_stride + (long)(sq % inner) * P.inner_stride + (long)lp * P.tok_stride) / P.C;
+        }
+        f32x4 aq[TT][2], ak[TT][2], av[TT][2];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { aq[tt][t] = bq[t]; ak[tt][t] = bk[t]; av[tt][t] = bv[t]; }
+        for (int kt = 0; kt < nkt; kt += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const uint4 wq = *reinterpret_cast<const uint4*>(wrow + (0 * 32 + t * 16) * RSW + (kt + u) * 64);
+                    const uint4 wk = *reinterpret_cast<const uint4*>(wrow + (1 * 32 + t * 16) * RSW + (kt + u) * 64);
+                    const uint4 wv = *reinterpret_cast<const uint4*>(wrow + (2 * 32 + t * 16) * RSW + (kt + u) * 64);
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) {
+                        M::mma(aq[tt][t], wq, ring[u][tt]);
+                        M::mma(ak[tt][t], wk, ring[u][tt]);
+                        M::mma(av[tt][t], ring[u][tt], wv);           // swapped: rows = tokens, cols = d
+                    }
+                }
+                fetch(ring[u]);
             }
         }
-        f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};                 // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
-        M::mma16(sc, ak[0], aq[0]);
-        M::mma16(sc, ak[1], aq[1]);
-        if (masked) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (4 * q + r >= P.L) sc[r] = -1e30f;
-        }
-        const float mx = max_q(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
-        float sum = 0.f;
+        for (int tt = 0; tt < TT; ++tt) {
+            f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};                     // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
+            M::mma16(sc, ak[tt][0], aq[tt][0]);
+            M::mma16(sc, ak[tt][1], aq[tt][1]);
+            if (masked) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { sc[r] = __builtin_amdgcn_exp2f((sc[r] - mx) * escale); sum += sc[r]; }
-        const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
+                for (int r = 0; r < 4; ++r) if (4 * q + r >= P.L) sc[r] = -1e30f;
+            }
+            const float mx = max_q(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+            float sum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sc[r] *= inv;
-        const size_t orow = (size_t)(ro / P.C) * HD + h * D;          // strides are multiples of C: ro / C = row index
+            for (int r = 0; r < 4; ++r) { sc[r] = __builtin_amdgcn_exp2f((sc[r] - mx) * escale); sum += sc[r]; }
+            const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-            M::mma16(o, av[t], sc);
-            if (tv) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.oscratch) + (orow + t * 16 + 4 * q) * 2) =
-                        make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            for (int r = 0; r < 4; ++r) sc[r] *= inv;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                M::mma16(o, av[tt][t], sc);
+                if (crow[tt] >= 0) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.oscratch) + ((size_t)crow[tt] * HD + h * D + t * 16 + 4 * q) * 2) =
+                                       make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+            }
         }
     }
 }
 
 hipError_t launch_attention_heads(AttnArgs a, hipStream_t st) {
     a.CPad = conv_cin_pad(MODE_BF16, a.C);
-    if (a.heads != 8 || a.L > 16 || a.C % 32 || !a.oscratch) return hipErrorInvalidValue;
+    if (a.heads != 8 || a.L > 16 || a.C % 128 || !a.oscratch || a.nseq >= (1L << 30)) return hipErrorInvalidValue;
     const size_t lds = (size_t)96 * (a.C * 2 + 32);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    // enough workgroups per head to fill the chip twice, at least 16 sequences (2 per wave) each
-    long spb = std::max<long>(16, (a.nseq * a.heads + 511) / 512);
-    spb = (spb + 7) / 8 * 8;
+    constexpr int TT = 4;
+    // enough workgroups per head to fill the chip twice, at least one group of TT sequences per wave each
+    long spb = std::max<long>(8 * TT, (a.nseq * a.heads + 511) / 512);
+    spb = (spb + 8 * TT - 1) / (8 * TT) * (8 * TT);
     const long chunks = (a.nseq + spb - 1) / spb;
     auto go = [&](auto kfn) -> hipError_t {
         if (lds > 64 * 1024) {
@@ -727,7 +774,7 @@ hipError_t launch_attention_heads(AttnArgs a, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3(a.heads, (unsigned)chunks), dim3(512), lds, st, a, (int)spb);
         return hipGetLastError();
     };
-    return a.io_bf16 ? go(attention_head_kernel<true>) : go(attention_head_kernel<false>);
+    return a.io_bf16 ? go(attention_head_kernel<true, TT>) : go(attention_head_kernel<false, TT>);
 }
 
 template <int MODE, int TMA>

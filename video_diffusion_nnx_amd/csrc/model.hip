@@ -401,7 +401,7 @@ static hipError_t run_attn(const Fwd& f, const AttnP& ap, const float* x, float*
     a.io_bf16 = f.a16;
     // wide levels in bf16 mode: per-head kernel (weights resident in LDS) + the out-projection as a 1x1 conv; VDX_ATTN_HEADS=0 disables
     static const int use_heads = getenv("VDX_ATTN_HEADS") ? atoi(getenv("VDX_ATTN_HEADS")) : 1;
-    if (use_heads && m->mode == MODE_BF16 && temporal && a.L <= 16 && a.heads == 8 && ap.C >= 256 && ap.C % 32 == 0 &&
+    if (use_heads && m->mode == MODE_BF16 && temporal && a.L <= 16 && a.heads == 8 && ap.C >= 256 && ap.C % 128 == 0 &&
         (size_t)96 * (ap.C * 2 + 32) <= 160 * 1024 && (size_t)Fr * S * S * a.heads * 64 <= m->sla_ws_bytes_per_sample) {
         a.oscratch = f.sla_ws;
         hipError_t e = launch_attention_heads(a, f.st);
@@ -425,6 +425,20 @@ static hipError_t run_sla(const Fwd& f, const SlaP& sp, const float* x, float* y
     a.x = x; a.y = y; a.wq = f.pk + sp.pk[0]; a.wk = f.pk + sp.pk[1]; a.wv = f.pk + sp.pk[2]; a.wo = f.pk + sp.pk_o;
     a.workspace = f.sla_ws; a.C = sp.C; a.heads = m->cfg.attn_heads; a.NF = f.B * m->cfg.num_frames; a.N = S * S;
     a.io_bf16 = f.a16;
+    // wide levels in bf16 mode: per-head kernel (weights resident in LDS) + to_out as a 1x1 conv; VDX_SLA_HEADS=0 disables
+    static const int use_heads = getenv("VDX_SLA_HEADS") ? atoi(getenv("VDX_SLA_HEADS")) : 1;
+    if (use_heads && m->mode == MODE_BF16 && a.heads == 8 && sp.C >= 256 && sp.C % 128 == 0 && a.N % 16 == 0 &&
+        (size_t)96 * (sp.C * 2 + 32) <= 160 * 1024 && (size_t)m->cfg.num_frames * a.N * a.heads * 64 <= m->sla_ws_bytes_per_sample) {
+        hipError_t e = launch_sla_heads(a, f.sla_ws, f.st);
+        if (e != hipSuccess) return e;
+        ConvArgs c;
+        memset(&c, 0, sizeof(c));
+        c.x0 = reinterpret_cast<const float*>(f.sla_ws); c.C0 = a.heads * 32; c.x0_bf16 = 1;
+        c.wp = f.pk + sp.pk_o; c.y = y; c.Cout = sp.C; c.y_bf16 = f.a16;
+        c.res = x; c.res_bf16 = f.a16;
+        c.NF = a.NF; c.F = m->cfg.num_frames; c.H = S; c.W = S; c.kind = 0; c.kh = c.kw = 1; c.stride = 1; c.pad = 0;
+        return launch_conv(m->mode, c, f.st);
+    }
     return launch_sla(m->mode, a, f.st);
 }
 

@@ -675,6 +675,187 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
     }
 }
 
+// ---- wide levels (C >= 256): one workgroup per (head, chunk of frames), one wave per frame ------------------------------------------
+// The head's q/k/v weight rows (96 x C bf16) are loaded into LDS once per workgroup; each wave then owns whole frames and needs no
+// workgroup barrier, no partials and no combine pass: phase 1 walks the frame's pixels in steps of 16*TT with the k/v projections
+// computed transposed (rows = pixels), so the softmax-over-pixels statistics are in-lane + quad reductions and e^T v is an MFMA over
+// the pixel index with the accumulators as operands; the 32x32 context stays in registers.  Phase 2 walks the pixels again (x is hot
+// in L2): q projection, softmax over D, out = ctx^T q -> O[row][head*32 + e] bf16.  to_out (+ residual) is a plain 1x1 conv_igemm.
+template <bool IO16, int TT>
+__global__ __launch_bounds__(512) void sla_head_kernel(const SlaArgs P, void* __restrict__ O, const int frames_per_block) {
+    using M = Mma<MODE_BF16>;
+    constexpr int D = 32;
+    constexpr float L2E = 1.44269504088896f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // W_h [q 32 | k 32 | v 32 rows][C * 2 + 32]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    const int h = blockIdx.x, HD = P.heads * D;
+    const int RSW = P.C * 2 + 32;
+    const int cpr = P.C / 8;
+    for (int i = tid; i < 96 * cpr; i += 512) {
+        const int row = i / cpr, pc = i - row * cpr;
+        const int part = row >> 5, rr = row & 31;
+        const char* src = reinterpret_cast<const char*>(part == 0 ? P.wq : part == 1 ? P.wk : P.wv);
+        *reinterpret_cast<uint4*>(smem + row * RSW + pc * 16) =
+            *reinterpret_cast<const uint4*>(src + ((size_t)(h * D + rr) * P.CPad) * 2 + pc * 16);
+    }
+    __syncthreads();
+    const int nkt = P.C / 32;
+    const char* wrow = smem + lp * RSW + q * 16;
+    const int n_end = min(P.NF, (int)(blockIdx.y + 1) * frames_per_block);
+    auto xload = [&](size_t e) -> uint4 {                              // 8 consecutive channels at element offset e as bf16
+        if (IO16) return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.x) + e * 2);
+        const float4 a = *reinterpret_cast<const float4*>(P.x + e), b = *reinterpret_cast<const float4*>(P.x + e + 4);
+        return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+    };
+    for (int n = blockIdx.y * frames_per_block + w; n < n_end; n += 8) {
+        const size_t xbase = (size_t)n * P.N * P.C + (size_t)lp * P.C + 8 * q;     // token lp of the frame, channel group q
+        // x fragments run through a 4-deep register ring: global loads are issued four K steps ahead of their use.  The walk is
+        // pixels 0..N (phase 1) and then 0..N again (phase 2), so the ring simply wraps once.
+        int ftok = 0, fk = 0, fpass = 0;
+        uint4 ring[4][TT];
+        auto fetch = [&](uint4 (&dst)[TT]) {
+            if (fpass < 2) {
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) dst[tt] = xload(xbase + (size_t)(ftok + tt * 16) * P.C + fk * 32);
+            }
+            if (++fk == nkt) { fk = 0; ftok += 16 * TT; if (ftok >= P.N) { ftok = 0; ++fpass; } }
+        };
+        // ---------------- phase 1: ctx[d, e] = sum_n softmax_n(k)[d, n] v[e, n] ----------------
+        float mrun[2] = {-1e30f, -1e30f}, srun[2] = {0.f, 0.f};                        // per d = t*16 + lp (replicated over q)
+        f32x4 ctx[2][2];                                                               // [dt][et]: rows d = 4q+r, cols e = lp
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { ctx[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; ctx[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        ftok = 0; fk = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fetch(ring[u]);
+        for (int tok0 = 0; tok0 < P.N; tok0 += 16 * TT) {
+            f32x4 ak[TT][2], av[TT][2];                                                // rows = pixels 4q+r, cols = d / e = lp
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) { ak[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f}; av[tt][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int kt = 0; kt < nkt; kt += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const uint4 wk = *reinterpret_cast<const uint4*>(wrow + (32 + t * 16) * RSW + (kt + u) * 64);
+                        const uint4 wv = *reinterpret_cast<const uint4*>(wrow + (64 + t * 16) * RSW + (kt + u) * 64);
+#pragma unroll
+                        for (int tt = 0; tt < TT; ++tt) { M::mma(ak[tt][t], ring[u][tt], wk); M::mma(av[tt][t], ring[u][tt], wv); }
+                    }
+                    fetch(ring[u]);
+                }
+            }
+            float al[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float mx = -1e30f;
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) mx = fmaxf(mx, fmaxf(fmaxf(ak[tt][t][0], ak[tt][t][1]), fmaxf(ak[tt][t][2], ak[tt][t][3])));
+                mx = max_q(mx);
+                const float mn = fmaxf(mrun[t], mx);
+                al[t] = __builtin_amdgcn_exp2f((mrun[t] - mn) * L2E);
+                mrun[t] = mn;
+                float sum = 0.f;
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ak[tt][t][r] = __builtin_amdgcn_exp2f((ak[tt][t][r] - mn) * L2E); sum += ak[tt][t][r]; }
+                srun[t] = srun[t] * al[t] + reduce_q(sum);
+            }
+            if (tok0 > 0) {                                                            // rescale: alpha of row d = 4q+r lives in lane 4q+r
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((4 * q + r) * 4, __builtin_bit_cast(int, al[dt])));
+                        ctx[dt][0][r] *= a; ctx[dt][1][r] *= a;
+                    }
+            }
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int et = 0; et < 2; ++et) M::mma16(ctx[dt][et], ak[tt][dt], av[tt][et]);
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const float inv = __builtin_amdgcn_rcpf(srun[dt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((4 * q + r) * 4, __builtin_bit_cast(int, inv)));
+                ctx[dt][0][r] *= a; ctx[dt][1][r] *= a;
+            }
+        }
+        // ---------------- phase 2: out[e, n] = sum_d ctx[d, e] softmax_d(q)[d, n] ----------------
+        const size_t obase = ((size_t)n * P.N + lp) * HD + h * D + 4 * q;
+        for (int tok0 = 0; tok0 < P.N; tok0 += 16 * TT) {
+            f32x4 aq[TT][2];                                                           // rows d = 4q+r, cols = pixels lp
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) { aq[tt][0] = f32x4{0.f, 0.f, 0.f, 0.f}; aq[tt][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int kt = 0; kt < nkt; kt += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const uint4 wq = *reinterpret_cast<const uint4*>(wrow + (t * 16) * RSW + (kt + u) * 64);
+#pragma unroll
+                        for (int tt = 0; tt < TT; ++tt) M::mma(aq[tt][t], wq, ring[u][tt]);
+                    }
+                    fetch(ring[u]);
+                }
+            }
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) {
+                float mx = fmaxf(fmaxf(fmaxf(aq[tt][0][0], aq[tt][0][1]), fmaxf(aq[tt][0][2], aq[tt][0][3])),
+                                 fmaxf(fmaxf(aq[tt][1][0], aq[tt][1][1]), fmaxf(aq[tt][1][2], aq[tt][1][3])));
+                mx = max_q(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { aq[tt][t][r] = __builtin_amdgcn_exp2f((aq[tt][t][r] - mx) * L2E); sum += aq[tt][t][r]; }
+                const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) aq[tt][t][r] *= inv;
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                    M::mma16(o, ctx[0][et], aq[tt][0]);
+                    M::mma16(o, ctx[1][et], aq[tt][1]);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(O) + (obase + (size_t)(tok0 + tt * 16) * HD + et * 16) * 2) =
+                        make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                }
+            }
+        }
+    }
+}
+
+hipError_t launch_sla_heads(SlaArgs a, void* O, hipStream_t st) {
+    a.CPad = conv_cin_pad(MODE_BF16, a.C);
+    if (a.heads != 8 || a.C % 128 || a.N % 16 || !O) return hipErrorInvalidValue;
+    const size_t lds = (size_t)96 * (a.C * 2 + 32);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    long fpb = (a.NF * (long)a.heads + 255) / 256;       // one round of workgroups over the chip (one 8-wave workgroup per CU: ~200 VGPRs)
+    fpb = std::max<long>(8, (fpb + 7) / 8 * 8);
+    const long chunks = (a.NF + fpb - 1) / fpb;
+    auto go = [&](auto kfn) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kfn, dim3(a.heads, (unsigned)chunks), dim3(512), lds, st, a, O, (int)fpb);
+        return hipGetLastError();
+    };
+    if (a.N % 64 == 0) return a.io_bf16 ? go(sla_head_kernel<true, 4>) : go(sla_head_kernel<false, 4>);
+    return a.io_bf16 ? go(sla_head_kernel<true, 1>) : go(sla_head_kernel<false, 1>);
+}
+
 // ---- host side -----------------------------------------------------------------------------------------
 
 void sla_plan(int N, int& nsub, int& nchunk) {

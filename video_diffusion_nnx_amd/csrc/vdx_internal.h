@@ -100,6 +100,9 @@ struct SlaArgs {
 };
 size_t sla_workspace_bytes(int mode, int NF, int N, int heads);
 hipError_t launch_sla(int mode, SlaArgs a, hipStream_t st);
+// bf16 mode, 8 heads, N % 16 == 0: per-head kernel (weights resident in LDS, one wave per frame) -> O [NF * N rows][heads * 32] bf16;
+// to_out + residual is a 1x1 conv_igemm by the caller
+hipError_t launch_sla_heads(SlaArgs a, void* O, hipStream_t st);
 
 struct PSampleArgs {
     const float* x; const float* eps; float* out;       // x/out [B,C,F,H,W] (may alias); eps channel-last [B,F,H,W,C]
