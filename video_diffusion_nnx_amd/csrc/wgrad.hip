@@ -191,8 +191,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* row0, const char* row1) {
 
 // NT taps per workgroup, split over NG groups of 4 waves (NTW = taps per wave): fewer live accumulators, and NG x 256 threads
 // share the staging of the same patch.
-template <int NT, int NG>
-__global__ __launch_bounds__(256 * NG) void conv_wgrad16_kernel(const WgradArgs P) {
+template <int NT, int NG, bool PF>
+__global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel(const WgradArgs P) {
     constexpr int NTH = 256 * NG;
     constexpr int NTW = (NT + NG - 1) / NG;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -241,13 +241,51 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad16_kernel(const WgradArgs 
     // transposing-read lane roles: group g = q supplies positions 8g..8g+7 of a 32-position K block; inside the group lane
     // 4*qr + pc supplies row qr (and qr + 4 for the second read), 8-byte column chunk pc
     const int qr = r >> 2, pcz = r & 3;
-    for (long pid = blockIdx.x; pid < total_patches; pid += gridDim.x) {
+    // Staging is software-pipelined: the global loads of the NEXT patch are issued into registers (ra / rb) right after the barrier
+    // that publishes the current patch, so they are in flight during the MFMA loop (one workgroup per CU: nothing else would hide them).
+    constexpr int XA = 6, XB = 4;                             // float4 pieces per thread (launcher checks HPX * 16 <= XA * NTH, BPX * 16 <= XB * NTH)
+    float4 ra[XA], rb[XB];
+    unsigned va = 0;                                          // in-bounds mask of ra (the prologue applies to in-bounds pixels only)
+    auto load_patch = [&](long pid) {
         const int f = (int)(pid / patches_per_frame);
         const int pr = (int)(pid % patches_per_frame);
         const int ty = pr / tiles_x, tx = pr % tiles_x;
         const int my0 = ty * P.PH, mx0 = tx * P.PW;
         const int iy0 = my0 * P.sa - P.halo, ix0 = mx0 * P.sa - P.halo;
-        const int b = f / P.F;
+        va = 0;
+#pragma unroll
+        for (int u = 0; u < XA; ++u) {
+            const int i = tid + u * NTH;
+            ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < HPX * 16) {
+                const int hp = i >> 4, pc = i & 15;
+                const int iy = div_magic(hp, P.m_iw), ix = hp - iy * IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                const int c = ci0 + pc * 4;
+                if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin) {
+                    const size_t pix = ((size_t)f * P.H + gy) * P.W + gx;
+                    ra[u] = (c < P.C0) ? load4_f32_or_bf16(P.x0, pix * P.C0 + c, P.x0_bf16)
+                                       : *reinterpret_cast<const float4*>(P.x1 + pix * P.C1 + (c - P.C0));
+                    va |= 1u << u;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+            const int i = tid + u * NTH;
+            rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < BPX * 16) {
+                const int bp = i >> 4, pc = i & 15;
+                const int yy = div_magic(bp, P.m_bw), xx = bp - yy * BW;
+                const int gy = my0 * P.sb + yy, gx = mx0 * P.sb + xx;
+                const int c = co0 + pc * 4;
+                if (gy < P.Hy && gx < P.Wy && c < P.Cout) rb[u] = load4_f32_or_bf16(P.dy, (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c, P.dy_bf16);
+            }
+        }
+    };
+    if (PF && (long)blockIdx.x < total_patches) load_patch(blockIdx.x);
+    for (long pid = blockIdx.x; pid < total_patches; pid += gridDim.x) {
+        const int b = (int)(pid / patches_per_frame) / P.F;
         __syncthreads();                                      // previous patch fully consumed
         if (P.pro && b != last_b) {
             if (tid < P.groups) {
@@ -272,36 +310,70 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad16_kernel(const WgradArgs 
             last_b = b;
             __syncthreads();
         }
-        for (int i = tid; i < HPX * 16; i += NTH) {
-            const int hp = i >> 4, pc = i & 15;
-            const int iy = div_magic(hp, P.m_iw), ix = hp - iy * IW;
-            const int gy = iy0 + iy, gx = ix0 + ix;
-            const int c = ci0 + pc * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin) {
-                const size_t pix = ((size_t)f * P.H + gy) * P.W + gx;
-                v = (c < P.C0) ? load4_f32_or_bf16(P.x0, pix * P.C0 + c, P.x0_bf16)
-                               : *reinterpret_cast<const float4*>(P.x1 + pix * P.C1 + (c - P.C0));
-                if (P.pro) {
-                    const float4 a = *reinterpret_cast<const float4*>(coefA + pc * 4);
-                    const float4 d = *reinterpret_cast<const float4*>(coefD + pc * 4);
-                    v.x = silu_f(fmaf(v.x, a.x, d.x)); v.y = silu_f(fmaf(v.y, a.y, d.y));
-                    v.z = silu_f(fmaf(v.z, a.z, d.z)); v.w = silu_f(fmaf(v.w, a.w, d.w));
+        if constexpr (PF) {
+#pragma unroll
+            for (int u = 0; u < XA; ++u) {
+                const int i = tid + u * NTH;
+                if (i < HPX * 16) {
+                    const int hp = i >> 4, pc = i & 15;
+                    float4 v = ra[u];
+                    if (P.pro && ((va >> u) & 1u)) {
+                        const float4 a = *reinterpret_cast<const float4*>(coefA + pc * 4);
+                        const float4 d = *reinterpret_cast<const float4*>(coefD + pc * 4);
+                        v.x = silu_f(fmaf(v.x, a.x, d.x)); v.y = silu_f(fmaf(v.y, a.y, d.y));
+                        v.z = silu_f(fmaf(v.z, a.z, d.z)); v.w = silu_f(fmaf(v.w, a.w, d.w));
+                    }
+                    *reinterpret_cast<uint2*>(As + (size_t)hp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
                 }
             }
-            *reinterpret_cast<uint2*>(As + (size_t)hp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
-        }
-        for (int i = tid; i < BPX * 16; i += NTH) {
-            const int bp = i >> 4, pc = i & 15;
-            const int yy = div_magic(bp, P.m_bw), xx = bp - yy * BW;
-            const int gy = my0 * P.sb + yy, gx = mx0 * P.sb + xx;
-            const int c = co0 + pc * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < P.Hy && gx < P.Wy && c < P.Cout) v = load4_f32_or_bf16(P.dy, (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c, P.dy_bf16);
-            bias4.x += v.x; bias4.y += v.y; bias4.z += v.z; bias4.w += v.w;
-            *reinterpret_cast<uint2*>(Bs + (size_t)bp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+#pragma unroll
+            for (int u = 0; u < XB; ++u) {
+                const int i = tid + u * NTH;
+                if (i < BPX * 16) {
+                    const int bp = i >> 4, pc = i & 15;
+                    const float4 v = rb[u];
+                    bias4.x += v.x; bias4.y += v.y; bias4.z += v.z; bias4.w += v.w;
+                    *reinterpret_cast<uint2*>(Bs + (size_t)bp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                }
+            }
+        } else {                                              // single-tap tiles: many small workgroups per CU hide the loads; stage in place
+            const int f = (int)(pid / patches_per_frame);
+            const int pr = (int)(pid % patches_per_frame);
+            const int ty = pr / tiles_x, tx = pr % tiles_x;
+            const int my0 = ty * P.PH, mx0 = tx * P.PW;
+            const int iy0 = my0 * P.sa - P.halo, ix0 = mx0 * P.sa - P.halo;
+            for (int i = tid; i < HPX * 16; i += NTH) {
+                const int hp = i >> 4, pc = i & 15;
+                const int iy = div_magic(hp, P.m_iw), ix = hp - iy * IW;
+                const int gy = iy0 + iy, gx = ix0 + ix;
+                const int c = ci0 + pc * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin) {
+                    const size_t pix = ((size_t)f * P.H + gy) * P.W + gx;
+                    v = (c < P.C0) ? load4_f32_or_bf16(P.x0, pix * P.C0 + c, P.x0_bf16)
+                                   : *reinterpret_cast<const float4*>(P.x1 + pix * P.C1 + (c - P.C0));
+                    if (P.pro) {
+                        const float4 a = *reinterpret_cast<const float4*>(coefA + pc * 4);
+                        const float4 d = *reinterpret_cast<const float4*>(coefD + pc * 4);
+                        v.x = silu_f(fmaf(v.x, a.x, d.x)); v.y = silu_f(fmaf(v.y, a.y, d.y));
+                        v.z = silu_f(fmaf(v.z, a.z, d.z)); v.w = silu_f(fmaf(v.w, a.w, d.w));
+                    }
+                }
+                *reinterpret_cast<uint2*>(As + (size_t)hp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+            }
+            for (int i = tid; i < BPX * 16; i += NTH) {
+                const int bp = i >> 4, pc = i & 15;
+                const int yy = div_magic(bp, P.m_bw), xx = bp - yy * BW;
+                const int gy = my0 * P.sb + yy, gx = mx0 * P.sb + xx;
+                const int c = co0 + pc * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy < P.Hy && gx < P.Wy && c < P.Cout) v = load4_f32_or_bf16(P.dy, (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c, P.dy_bf16);
+                bias4.x += v.x; bias4.y += v.y; bias4.z += v.z; bias4.w += v.w;
+                *reinterpret_cast<uint2*>(Bs + (size_t)bp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+            }
         }
         __syncthreads();
+        if (PF && pid + gridDim.x < total_patches) load_patch(pid + gridDim.x);
         // ---- K loop: 32 patch positions per MFMA (a lane group's 8 positions are consecutive in one patch row) ----
         const int npos = P.PH * P.PW;
         for (int k0 = 0; k0 < npos; k0 += 32) {
@@ -311,13 +383,15 @@ __global__ __launch_bounds__(256 * NG) void conv_wgrad16_kernel(const WgradArgs 
             const char* a1 = As + (size_t)((py1 * P.sa) * IW + px1 * P.sa) * WG_RSB + wi * 64 + pcz * 8;
             const char* b0 = Bs + (size_t)((py0 * P.sb) * BW + px0 * P.sb) * WG_RSB + wo * 64 + pcz * 8;
             const char* b1 = Bs + (size_t)((py1 * P.sb) * BW + px1 * P.sb) * WG_RSB + wo * 64 + pcz * 8;
+            // kind 0: dy is not shifted by the tap, so its fragments are read once per K block and reused by every tap of the wave
+            bf16x8 bf0, bf1;
+            if (P.kind == 0) { bf0 = tr_frag(b0, b1); bf1 = tr_frag(b0 + 32, b1 + 32); }
 #pragma unroll
             for (int tt = 0; tt < NTW; ++tt) {
                 const int t = min(tw0 + tt, NT - 1);          // a wave past the last tap repeats it (EXEC stays full); never stored
                 const bf16x8 af0 = tr_frag(a0 + tapA[t], a1 + tapA[t]);
                 const bf16x8 af1 = tr_frag(a0 + tapA[t] + 32, a1 + tapA[t] + 32);
-                const bf16x8 bf0 = tr_frag(b0 + tapB[t], b1 + tapB[t]);
-                const bf16x8 bf1 = tr_frag(b0 + tapB[t] + 32, b1 + tapB[t] + 32);
+                if (P.kind != 0) { bf0 = tr_frag(b0 + tapB[t], b1 + tapB[t]); bf1 = tr_frag(b0 + tapB[t] + 32, b1 + tapB[t] + 32); }
                 acc[tt][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[tt][0][0], 0, 0, 0);
                 acc[tt][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[tt][0][1], 0, 0, 0);
                 acc[tt][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[tt][1][0], 0, 0, 0);
@@ -414,16 +488,24 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
     const size_t lds = ((size_t)IH * IW + (size_t)a.PH * a.sb * a.PW * a.sb) * WG_LD * 4 + 3 * 64 * 4 + 32 * 4;
     const long patches = (long)a.NF * ((a.Hm + a.PH - 1) / a.PH) * ((a.Wm + a.PW - 1) / a.PW);
     const long tiles = (long)ci_tiles * a.co_tiles * tap_groups;
-    long chunks = std::max<long>(1, std::min<long>(patches, 1024 / std::max<long>(1, tiles)));
+    static const long target_wgs = getenv("VDX_WGRAD_WGS") ? atol(getenv("VDX_WGRAD_WGS")) : 1024;
+    // multi-tap tiles: the epilogue is 64 x 64 x NT atomic adds per workgroup and the chip sustains about one 256-byte atomic wave
+    // instruction per 50 ns per CU, so 1024 workgroups spend ~115 us in the epilogue alone; 256 (one per CU) measured best
+    static const long target_wgs9 = getenv("VDX_WGRAD_WGS9") ? atol(getenv("VDX_WGRAD_WGS9")) : 256;
+    long chunks = std::max<long>(1, std::min<long>(patches, (a.taps > 1 ? target_wgs9 : target_wgs) / std::max<long>(1, tiles)));
     dim3 grid((unsigned)chunks, ci_tiles, a.co_tiles * tap_groups);
     if (a.bf16_mma && (a.PW == 8 || a.PW == 16)) {
         a.pwl = a.PW == 8 ? 3 : 4;
         const size_t lds16 = ((size_t)IH * IW + (size_t)a.PH * a.sb * a.PW * a.sb) * WG_RSB + 4 * 64 * 4 + 32 * 4;
-#define VDX_WG16(NT_, NG_) do { auto kfn = conv_wgrad16_kernel<NT_, NG_>;                                                \
+#define VDX_WG16(NT_, NG_) do { auto kfn = conv_wgrad16_kernel<NT_, NG_, (NT_ > 1)>;                                                \
         if (lds16 > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16); if (e != hipSuccess) return e; } \
         hipLaunchKernelGGL(kfn, grid, dim3(256 * NG_), lds16, st, a); } while (0)
         a.m_iw = (unsigned)((1ull << 32) / (unsigned)IW) + 1u;
         a.m_bw = (unsigned)((1ull << 32) / (unsigned)(a.PW * a.sb)) + 1u;
+        {   // register staging capacity of conv_wgrad16_kernel (XA = 6, XB = 4 float4 pieces per thread)
+            const long nth = NT == 1 ? 256 : 512;
+            if ((long)IH * IW * 16 > 6 * nth || (long)a.PH * a.sb * a.PW * a.sb * 16 > 4 * nth) return hipErrorInvalidValue;
+        }
         if (NT == 1) VDX_WG16(1, 1); else if (NT == 9) VDX_WG16(9, 2); else VDX_WG16(8, 2);
 #undef VDX_WG16
         return hipGetLastError();
