@@ -191,7 +191,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* row0, const char* row1) {
 
 // NT taps per workgroup, split over NG groups of 4 waves (NTW = taps per wave): fewer live accumulators, and NG x 256 threads
 // share the staging of the same patch.
-template <int NT, int NG, bool PF>
+template <int NT, int NG, bool PF, bool X16, bool DY16>
 __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel(const WgradArgs P) {
     constexpr int NTH = 256 * NG;
     constexpr int NTW = (NT + NG - 1) / NG;
@@ -246,45 +246,60 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel
     constexpr int XA = 6, XB = 4;                             // float4 pieces per thread (launcher checks HPX * 16 <= XA * NTH, BPX * 16 <= XB * NTH)
     float4 ra[XA], rb[XB];
     unsigned va = 0;                                          // in-bounds mask of ra (the prologue applies to in-bounds pixels only)
+    // Every piece is loaded unconditionally (out-of-range pieces read the tensor base and are masked when stored) and kept as raw
+    // bits: no branch and no conversion between a load and the next one, so all XA + XB loads of a thread are in flight together.
+    unsigned vb = 0;
     auto load_patch = [&](long pid) {
         const int f = (int)(pid / patches_per_frame);
         const int pr = (int)(pid % patches_per_frame);
         const int ty = pr / tiles_x, tx = pr % tiles_x;
         const int my0 = ty * P.PH, mx0 = tx * P.PW;
         const int iy0 = my0 * P.sa - P.halo, ix0 = mx0 * P.sa - P.halo;
-        va = 0;
+        va = 0; vb = 0;
 #pragma unroll
         for (int u = 0; u < XA; ++u) {
             const int i = tid + u * NTH;
-            ra[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < HPX * 16) {
-                const int hp = i >> 4, pc = i & 15;
-                const int iy = div_magic(hp, P.m_iw), ix = hp - iy * IW;
-                const int gy = iy0 + iy, gx = ix0 + ix;
-                const int c = ci0 + pc * 4;
-                if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin) {
-                    const size_t pix = ((size_t)f * P.H + gy) * P.W + gx;
-                    ra[u] = (c < P.C0) ? load4_f32_or_bf16(P.x0, pix * P.C0 + c, P.x0_bf16)
-                                       : *reinterpret_cast<const float4*>(P.x1 + pix * P.C1 + (c - P.C0));
-                    va |= 1u << u;
-                }
+            const int hp = i >> 4, pc = i & 15;
+            const int iy = div_magic(hp, P.m_iw), ix = hp - iy * IW;
+            const int gy = iy0 + iy, gx = ix0 + ix;
+            const int c = ci0 + pc * 4;
+            const bool ok = i < HPX * 16 && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin;
+            const size_t pix = ok ? ((size_t)f * P.H + gy) * P.W + gx : 0;
+            if (X16) {
+                const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.x0) + (ok ? (pix * P.C0 + c) * 2 : 0));
+                ra[u] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), 0.f, 0.f);
+            } else {
+                const float* src = (!ok || c < P.C0) ? P.x0 + (ok ? pix * P.C0 + c : 0) : P.x1 + pix * P.C1 + (c - P.C0);
+                ra[u] = *reinterpret_cast<const float4*>(src);
             }
+            va |= (ok ? 1u : 0u) << u;
         }
 #pragma unroll
         for (int u = 0; u < XB; ++u) {
             const int i = tid + u * NTH;
-            rb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < BPX * 16) {
-                const int bp = i >> 4, pc = i & 15;
-                const int yy = div_magic(bp, P.m_bw), xx = bp - yy * BW;
-                const int gy = my0 * P.sb + yy, gx = mx0 * P.sb + xx;
-                const int c = co0 + pc * 4;
-                if (gy < P.Hy && gx < P.Wy && c < P.Cout) rb[u] = load4_f32_or_bf16(P.dy, (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c, P.dy_bf16);
-            }
+            const int bp = i >> 4, pc = i & 15;
+            const int yy = div_magic(bp, P.m_bw), xx = bp - yy * BW;
+            const int gy = my0 * P.sb + yy, gx = mx0 * P.sb + xx;
+            const int c = co0 + pc * 4;
+            const bool ok = i < BPX * 16 && gy < P.Hy && gx < P.Wy && c < P.Cout;
+            const size_t e = ok ? (((size_t)f * P.Hy + gy) * P.Wy + gx) * P.Cout + c : 0;
+            if (DY16) {
+                const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.dy) + e * 2);
+                rb[u] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), 0.f, 0.f);
+            } else rb[u] = *reinterpret_cast<const float4*>(P.dy + e);
+            vb |= (ok ? 1u : 0u) << u;
         }
     };
-    if (PF && (long)blockIdx.x < total_patches) load_patch(blockIdx.x);
-    for (long pid = blockIdx.x; pid < total_patches; pid += gridDim.x) {
+    auto widen = [](const float4 v) {                         // 4 bf16 held as raw bits in v.x, v.y -> float4
+        const unsigned a = __float_as_uint(v.x), b = __float_as_uint(v.y);
+        return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xFFFF0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xFFFF0000u));
+    };
+    // consecutive patches per workgroup: the sample index (and with it the GroupNorm prologue coefficients) changes at most
+    // (patches per workgroup / patches per sample) + 1 times, and neighbouring patches share their halo rows in L2
+    const long p_per = (total_patches + gridDim.x - 1) / gridDim.x;
+    const long p_begin = (long)blockIdx.x * p_per, p_end = min(total_patches, p_begin + p_per);
+    if (PF && p_begin < p_end) load_patch(p_begin);
+    for (long pid = p_begin; pid < p_end; ++pid) {
         const int b = (int)(pid / patches_per_frame) / P.F;
         __syncthreads();                                      // previous patch fully consumed
         if (P.pro && b != last_b) {
@@ -316,7 +331,8 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel
                 const int i = tid + u * NTH;
                 if (i < HPX * 16) {
                     const int hp = i >> 4, pc = i & 15;
-                    float4 v = ra[u];
+                    float4 v = X16 ? widen(ra[u]) : ra[u];
+                    if (!((va >> u) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (P.pro && ((va >> u) & 1u)) {
                         const float4 a = *reinterpret_cast<const float4*>(coefA + pc * 4);
                         const float4 d = *reinterpret_cast<const float4*>(coefD + pc * 4);
@@ -331,7 +347,8 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel
                 const int i = tid + u * NTH;
                 if (i < BPX * 16) {
                     const int bp = i >> 4, pc = i & 15;
-                    const float4 v = rb[u];
+                    float4 v = DY16 ? widen(rb[u]) : rb[u];
+                    if (!((vb >> u) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     bias4.x += v.x; bias4.y += v.y; bias4.z += v.z; bias4.w += v.w;
                     *reinterpret_cast<uint2*>(Bs + (size_t)bp * WG_RSB + pc * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
                 }
@@ -373,7 +390,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel
             }
         }
         __syncthreads();
-        if (PF && pid + gridDim.x < total_patches) load_patch(pid + gridDim.x);
+        if (PF && pid + 1 < p_end) load_patch(pid + 1);
         // ---- K loop: 32 patch positions per MFMA (a lane group's 8 positions are consecutive in one patch row) ----
         const int npos = P.PH * P.PW;
         for (int k0 = 0; k0 < npos; k0 += 32) {
@@ -497,7 +514,7 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
     if (a.bf16_mma && (a.PW == 8 || a.PW == 16)) {
         a.pwl = a.PW == 8 ? 3 : 4;
         const size_t lds16 = ((size_t)IH * IW + (size_t)a.PH * a.sb * a.PW * a.sb) * WG_RSB + 4 * 64 * 4 + 32 * 4;
-#define VDX_WG16(NT_, NG_) do { auto kfn = conv_wgrad16_kernel<NT_, NG_, (NT_ > 1)>;                                                \
+#define VDX_WG16(NT_, NG_, PF_, X16_, DY16_) do { auto kfn = conv_wgrad16_kernel<NT_, NG_, PF_, X16_, DY16_>;                                                \
         if (lds16 > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16); if (e != hipSuccess) return e; } \
         hipLaunchKernelGGL(kfn, grid, dim3(256 * NG_), lds16, st, a); } while (0)
         a.m_iw = (unsigned)((1ull << 32) / (unsigned)IW) + 1u;
@@ -506,7 +523,14 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
             const long nth = NT == 1 ? 256 : 512;
             if ((long)IH * IW * 16 > 6 * nth || (long)a.PH * a.sb * a.PW * a.sb * 16 > 4 * nth) return hipErrorInvalidValue;
         }
-        if (NT == 1) VDX_WG16(1, 1); else if (NT == 9) VDX_WG16(9, 2); else VDX_WG16(8, 2);
+        if (a.x0_bf16 && a.C1) return hipErrorInvalidValue;      // the bf16 x0 form has no concat operand
+        static const bool pf1 = getenv("VDX_WGRAD_PF1") ? atoi(getenv("VDX_WGRAD_PF1")) != 0 : false;
+#define VDX_WG16_IO(NT_, NG_, PF_) do { if (a.x0_bf16) { if (a.dy_bf16) VDX_WG16(NT_, NG_, PF_, true, true); else VDX_WG16(NT_, NG_, PF_, true, false); } \
+                                        else { if (a.dy_bf16) VDX_WG16(NT_, NG_, PF_, false, true); else VDX_WG16(NT_, NG_, PF_, false, false); } } while (0)
+        if (NT == 1) { if (pf1) VDX_WG16_IO(1, 1, true); else VDX_WG16_IO(1, 1, false); }
+        else if (NT == 9) VDX_WG16_IO(9, 2, true);
+        else VDX_WG16_IO(8, 2, true);
+#undef VDX_WG16_IO
 #undef VDX_WG16
         return hipGetLastError();
     }
