@@ -27,6 +27,8 @@ CASES = [
     (1, 4, 8, 8, 32, 32, 4, 1, 1),        # Upsample
     (1, 2, 2, 2, 64, 64, 4, 1, 1),
     (1, 4, 8, 8, 48, 40, 1, 1, 0),        # pointwise
+    (1, 3, 5, 7, 72, 256, 1, 1, 0),       # pointwise, Cout % 256 == 0: split-K GEMM form of bf16 mode (ragged rows and channels)
+    (2, 4, 8, 8, 64, 768, 1, 1, 0),       # the q|k|v projection shape
 ]
 
 
@@ -104,6 +106,13 @@ def test_wgrad_concat_and_prologue():
     dw216 = ops.conv_backward_weights(y1.float().to(DEV), dy2.float().to(DEV), k2.shape, in_stats=stats.reshape(-1).to(DEV),
                                       gamma=gamma.float().to(DEV), beta=beta.float().to(DEV), scale_shift=ss.float().to(DEV), bf16_operands=True)
     assert _rel(dw216.cpu().double(), gk2) < 8e-3
+    # pointwise conv over a concat input, wide output (the split-K GEMM form of bf16 mode)
+    kp = (torch.randn(1, 1, 1, C0 + C1, 256, generator=g, dtype=torch.float64) / 7).requires_grad_(True)
+    yp = R.conv_pointwise(torch.cat((xa, xb), -1), kp[0], None)
+    dyp = torch.randn(yp.shape, generator=g, dtype=torch.float64)
+    (gkp,) = torch.autograd.grad(yp, kp, dyp)
+    dwp = ops.conv_backward_weights(xa.float().to(DEV), dyp.float().to(DEV), kp.shape, x1=xb.float().to(DEV), k=1, bf16_operands=True)
+    assert _rel(dwp.cpu().double(), gkp) < 8e-3
 
 
 @pytest.mark.parametrize('C,B,shape,use_ss,tail', [(16, 2, (3, 5, 5), True, False), (64, 2, (4, 8, 8), True, False), (64, 1, (2, 8, 8), False, True),

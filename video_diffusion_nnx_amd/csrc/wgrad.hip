@@ -10,6 +10,7 @@
 // single staged halo tile (<= 9 accumulator sets of 2x2 tiles per wave).  Split-K over pixel chunks; results are
 // added to the fp32 gradient buffer with float atomics (dW is tiny next to the activations).
 #include "vdx_common.h"
+#include <type_traits>
 #include "vdx_internal.h"
 #include <stdlib.h>
 
@@ -445,6 +446,177 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel
     }
 }
 
+// ---- 1x1 convolutions (projections) in bf16 mode: dW[Cin][Cout] += X^T dY as a split-K GEMM over the pixel rows -----------------------
+// Workgroup tile = 64 input channels x 64 * NCO output channels over a contiguous range of 64-row K tiles (wave (wi, wo): 32 ci x
+// NCO x 32 co).  With the q|k|v gradients in one [rows][768] tensor, NCO = 4 stages x three times instead of twelve.  All global
+// loads of a K tile are issued unconditionally as raw bits (out-of-range pieces read the tensor base and are zeroed when stored),
+// one tile ahead of the MFMA loop that consumes them.
+template <bool X16, bool DY16, int NCO>
+__global__ __launch_bounds__(256, NCO == 4 ? 2 : 4) void wgrad1x1_kernel(const WgradArgs P, const long rows, const int tiles_per_wg) {
+    constexpr int RSA = WG_RSB, RSBB = NCO * 128 + 16;
+    constexpr int XA = 4, XB = 4 * NCO;                           // 16-byte pieces per thread per K tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* As = smem;                                              // [64 rows][RSA]
+    char* Bs = As + 64 * RSA;                                     // [64 rows][RSBB]
+    float* bsum = reinterpret_cast<float*>(Bs + 64 * RSBB);      // [64 * NCO]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 15, q = lane >> 4, qr = r >> 2, pcz = r & 3;
+    const int wi = w & 1, wo = w >> 1;
+    const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64 * NCO;
+    const int Cin = P.C0 + P.C1;
+    const bool do_bias = P.db && blockIdx.y == 0;
+    for (int i = tid; i < 64 * NCO; i += 256) bsum[i] = 0.f;
+
+    f32x4 acc[NCO][2][2];
+#pragma unroll
+    for (int s = 0; s < NCO; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc[s][i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[s][i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);              // this thread's 4 output channels: (tid % (16 * NCO)) * 4
+
+    // raw pieces: 4 fp32 (float4) or 4 bf16 (uint2)
+    typename std::conditional<X16, uint2, float4>::type ra[XA];
+    typename std::conditional<DY16, uint2, float4>::type rb[XB];
+    unsigned va = 0, vb = 0;
+    // a thread's pieces sit at the same (row in tile, channel) for every tile: element offsets relative to the tile's first row are
+    // computed once; per tile only the (uniform) tile base and the row-tail mask change
+    unsigned offA[XA], offB[XB]; unsigned cokA = 0, cokB = 0, isx1 = 0;
+#pragma unroll
+    for (int u = 0; u < XA; ++u) {
+        const int i = tid + u * 256, rr = i >> 4, c = ci0 + (i & 15) * 4;
+        if (c < Cin) cokA |= 1u << u;
+        if (c >= P.C0) { isx1 |= 1u << u; offA[u] = (unsigned)(rr * P.C1 + (c - P.C0)); } else offA[u] = (unsigned)(rr * P.C0 + c);
+    }
+#pragma unroll
+    for (int u = 0; u < XB; ++u) {
+        const int i = tid + u * 256, rr = i / (16 * NCO), c = co0 + (i % (16 * NCO)) * 4;
+        if (c < P.Cout) cokB |= 1u << u;
+        offB[u] = (unsigned)(rr * P.Cout + c);
+    }
+    auto load_tile = [&](long t) {
+        const long row0 = t * 64;
+        const int left = (int)min((long)64, rows - row0);         // rows of this tile (uniform)
+        const char* xb0 = reinterpret_cast<const char*>(P.x0) + (size_t)row0 * P.C0 * (X16 ? 2 : 4);
+        const char* xb1 = reinterpret_cast<const char*>(P.x1) + (size_t)row0 * P.C1 * 4;
+        const char* yb = reinterpret_cast<const char*>(P.dy) + (size_t)row0 * P.Cout * (DY16 ? 2 : 4);
+        va = 0; vb = 0;
+#pragma unroll
+        for (int u = 0; u < XA; ++u) {
+            const bool ok = ((tid + u * 256) >> 4) < left && ((cokA >> u) & 1u);
+            const size_t o = ok ? (size_t)offA[u] : 0;
+            if constexpr (X16) ra[u] = *reinterpret_cast<const uint2*>(xb0 + o * 2);
+            else ra[u] = *reinterpret_cast<const float4*>((ok && ((isx1 >> u) & 1u) ? xb1 : xb0) + o * 4);
+            va |= (ok ? 1u : 0u) << u;
+        }
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+            const bool ok = ((tid + u * 256) / (16 * NCO)) < left && ((cokB >> u) & 1u);
+            const size_t o = ok ? (size_t)offB[u] : 0;
+            if constexpr (DY16) rb[u] = *reinterpret_cast<const uint2*>(yb + o * 2);
+            else rb[u] = *reinterpret_cast<const float4*>(yb + o * 4);
+            vb |= (ok ? 1u : 0u) << u;
+        }
+    };
+    auto widen = [](const uint2 v) {
+        const unsigned a = v.x, b = v.y;
+        return make_float4(__uint_as_float(a << 16), __uint_as_float(a & 0xFFFF0000u), __uint_as_float(b << 16), __uint_as_float(b & 0xFFFF0000u));
+    };
+    const long ntiles = (rows + 63) / 64;
+    const long t_begin = (long)blockIdx.x * tiles_per_wg, t_end = min(ntiles, t_begin + tiles_per_wg);
+    if (t_begin < t_end) load_tile(t_begin);
+    for (long t = t_begin; t < t_end; ++t) {
+        __syncthreads();                                          // previous tile fully consumed
+#pragma unroll
+        for (int u = 0; u < XA; ++u) {
+            const int i = tid + u * 256;
+            float4 v;
+            if constexpr (X16) v = widen(ra[u]); else v = ra[u];
+            if (!((va >> u) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            *reinterpret_cast<uint2*>(As + (i >> 4) * RSA + (i & 15) * 8) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+        }
+#pragma unroll
+        for (int u = 0; u < XB; ++u) {
+            const int i = tid + u * 256;
+            float4 v;
+            if constexpr (DY16) v = widen(rb[u]); else v = rb[u];
+            if (!((vb >> u) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bias4.x += v.x; bias4.y += v.y; bias4.z += v.z; bias4.w += v.w;
+            uint2 o;
+            if constexpr (DY16) o = ((vb >> u) & 1u) ? rb[u] : make_uint2(0u, 0u);
+            else o = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+            *reinterpret_cast<uint2*>(Bs + (i / (16 * NCO)) * RSBB + (i % (16 * NCO)) * 8) = o;
+        }
+        __syncthreads();
+        if (t + 1 < t_end) load_tile(t + 1);
+#pragma unroll 1
+        for (int k0 = 0; k0 < 64; k0 += 32) {
+            const int p0 = k0 + 8 * q + qr, p1 = p0 + 4;
+            const char* a0 = As + p0 * RSA + wi * 64 + pcz * 8;
+            const char* a1 = As + p1 * RSA + wi * 64 + pcz * 8;
+            const bf16x8 af0 = tr_frag(a0, a1), af1 = tr_frag(a0 + 32, a1 + 32);
+#pragma unroll
+            for (int s = 0; s < NCO; ++s) {
+                const char* b0 = Bs + p0 * RSBB + s * 128 + wo * 64 + pcz * 8;
+                const char* b1 = Bs + p1 * RSBB + s * 128 + wo * 64 + pcz * 8;
+                const bf16x8 bf0 = tr_frag(b0, b1), bf1 = tr_frag(b0 + 32, b1 + 32);
+                acc[s][0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf0, acc[s][0][0], 0, 0, 0);
+                acc[s][0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af0, bf1, acc[s][0][1], 0, 0, 0);
+                acc[s][1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf0, acc[s][1][0], 0, 0, 0);
+                acc[s][1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af1, bf1, acc[s][1][1], 0, 0, 0);
+            }
+        }
+    }
+    auto target = [&](int co, float*& dWt, float*& dbt, int& cbase, int& cw) {
+        const int sel = P.split ? co / P.split : 0;
+        cbase = P.split ? sel * P.split : 0; cw = P.split ? P.split : P.Cout;
+        dWt = sel == 0 ? P.dW : (sel == 1 ? P.dW1 : P.dW2);
+        dbt = sel == 0 ? P.db : (sel == 1 ? P.db1 : P.db2);
+    };
+    if (do_bias) {                                                // (uniform per workgroup)
+        const int pc = tid % (16 * NCO);
+        atomicAdd(&bsum[pc * 4 + 0], bias4.x); atomicAdd(&bsum[pc * 4 + 1], bias4.y);
+        atomicAdd(&bsum[pc * 4 + 2], bias4.z); atomicAdd(&bsum[pc * 4 + 3], bias4.w);
+        __syncthreads();
+        for (int i = tid; i < 64 * NCO; i += 256) {
+            const int co = co0 + i;
+            if (co < P.Cout) {
+                float* dWt; float* dbt; int cbase, cw;
+                target(co, dWt, dbt, cbase, cw);
+                if (dbt) atomicAdd(dbt + co - cbase, bsum[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NCO; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int co = co0 + s * 64 + wo * 32 + j * 16 + r;
+            if (co >= P.Cout) continue;
+            float* dWt; float* dbt; int cbase, cw;
+            target(co, dWt, dbt, cbase, cw);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ci = ci0 + wi * 32 + i * 16 + 4 * q + e;
+                    if (ci < Cin) atomicAdd(dWt + (size_t)ci * cw + co - cbase, acc[s][i][j][e]);
+                }
+        }
+}
+
+template <bool X16, bool DY16, int NCO>
+static hipError_t launch_wgrad1x1_t(const WgradArgs& a, long target_wgs, hipStream_t st) {
+    const long rows = (long)a.NF * a.H * a.W;
+    const int Cin = a.C0 + a.C1;
+    const int ci_tiles = (Cin + 63) / 64, co_tiles = (a.Cout + 64 * NCO - 1) / (64 * NCO);
+    const long ntiles = (rows + 63) / 64;
+    const long chunks = std::max<long>(1, std::min<long>(ntiles, target_wgs / ((long)ci_tiles * co_tiles)));
+    const int per = (int)((ntiles + chunks - 1) / chunks);
+    const size_t lds = 64 * WG_RSB + 64 * (NCO * 128 + 16) + 64 * NCO * 4;
+    hipLaunchKernelGGL((wgrad1x1_kernel<X16, DY16, NCO>), dim3((unsigned)((ntiles + per - 1) / per), ci_tiles, co_tiles), dim3(256), lds, st, a, rows, per);
+    return hipGetLastError();
+}
+
 // out[c] += sum over rows of x[row][c]   (bias / LayerNorm-beta gradients); x is [rows][C] fp32
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int C) {
     __shared__ float red[256];
@@ -524,6 +696,17 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
             if ((long)IH * IW * 16 > 6 * nth || (long)a.PH * a.sb * a.PW * a.sb * 16 > 4 * nth) return hipErrorInvalidValue;
         }
         if (a.x0_bf16 && a.C1) return hipErrorInvalidValue;      // the bf16 x0 form has no concat operand
+        // projections: the split-K GEMM form (wide output tiles when Cout allows: x is staged Cout / 256 times instead of Cout / 64)
+        static const int use_1x1 = getenv("VDX_WGRAD_1X1") ? atoi(getenv("VDX_WGRAD_1X1")) : 2;   // 0: patch kernel, 1: GEMM form for wide outputs only, 2: always
+        if (use_1x1 && NT == 1 && a.kind == 0 && a.stride == 1 && !a.pro && (a.Cout % 256 == 0 || use_1x1 == 2)) {
+            static const long wgs4 = getenv("VDX_WGRAD_WGS4") ? atol(getenv("VDX_WGRAD_WGS4")) : 512;
+            if (a.Cout % 256 == 0) {
+                if (a.x0_bf16) return a.dy_bf16 ? launch_wgrad1x1_t<true, true, 4>(a, wgs4, st) : launch_wgrad1x1_t<true, false, 4>(a, wgs4, st);
+                return a.dy_bf16 ? launch_wgrad1x1_t<false, true, 4>(a, wgs4, st) : launch_wgrad1x1_t<false, false, 4>(a, wgs4, st);
+            }
+            if (a.x0_bf16) return a.dy_bf16 ? launch_wgrad1x1_t<true, true, 1>(a, target_wgs, st) : launch_wgrad1x1_t<true, false, 1>(a, target_wgs, st);
+            return a.dy_bf16 ? launch_wgrad1x1_t<false, true, 1>(a, target_wgs, st) : launch_wgrad1x1_t<false, false, 1>(a, target_wgs, st);
+        }
         static const bool pf1 = getenv("VDX_WGRAD_PF1") ? atoi(getenv("VDX_WGRAD_PF1")) != 0 : false;
 #define VDX_WG16_IO(NT_, NG_, PF_) do { if (a.x0_bf16) { if (a.dy_bf16) VDX_WG16(NT_, NG_, PF_, true, true); else VDX_WG16(NT_, NG_, PF_, true, false); } \
                                         else { if (a.dy_bf16) VDX_WG16(NT_, NG_, PF_, false, true); else VDX_WG16(NT_, NG_, PF_, false, false); } } while (0)
