@@ -112,7 +112,8 @@ def time_conv_kernels(unet, frames, size, batch, mode, act='f32', reps=5):
         ms = e0.elapsed_time(e1) / reps
         mode_id = {'f32': 0, 'bf16': 1}[mode]                                              # rocprof prints the template arguments
         narrow = cout <= 64 and kind == 'down'                                           # launch_conv: TN = 2 / 4 waves; else 8 waves x TN 2
-        sym = f'vdx::conv_igemm_kernel<{mode_id}, {64 if cout <= 64 else 128}, 2, {4 if narrow else 8}>'
+        inf = 0 if act != 'bf16' else (2 if cin % 8 == 0 else 1)                        # launch_conv: input storage variant (fp32 / bf16 / 16-byte bf16)
+        sym = f'vdx::conv_igemm_kernel<{mode_id}, {64 if cout <= 64 else 128}, 2, {4 if narrow else 8}, {inf}>'
         if (mode == 'bf16' and kind in ('c3', 'c3p') and cin == 64 and cout == 64 and s % 16 == 0
                 and batch * frames * (s // 16) ** 2 >= 1024):                            # launch_conv's persistent level-0 specialisation
             b16 = 'true' if act == 'bf16' else 'false'                                    # template <IN16, PRO, OUT16>

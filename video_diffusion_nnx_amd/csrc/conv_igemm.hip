@@ -27,7 +27,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 constexpr unsigned OOB = 0xFFFFFFF0u;      // buffer-load offset beyond num_records: the hardware returns zeros
 
 // TN = 16-pixel tiles per wave (4: 64 pixels, 2: 32 pixels), NW = waves.  Workgroup tile = BC channels x BM pixels.
-template <int MODE, int BC, int TN, int NW>
+// INF = storage of the input tensors, fixed at compile time so that the staging loop is a straight batch of loads with no
+// format branch between them: 0 = fp32 (x0 and x1), 1 = bf16 x0 without concat, 2 = every input bf16 with channel counts that
+// are multiples of 8 (16-byte pieces), 3 = anything else (formats read from the descriptor at run time).
+template <int MODE, int BC, int TN, int NW, int INF>
 __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
     using M = Mma<MODE>;
     constexpr int KT = M::KT;
@@ -165,18 +168,23 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
 
     // ---- main loop: K tiles of cin x taps --------------------------------------------------------
     const int total = HPX * APIECES;
-    const bool in16 = P.x0_bf16 && (!P.C1 || P.x1_bf16) && (P.C0 % 8 == 0) && (P.C1 % 8 == 0);
+    constexpr bool RT = (INF == 3);
+    const bool x0b = RT ? (P.x0_bf16 != 0) : (INF == 1);
+    const bool x1b = RT ? (P.x1_bf16 != 0) : false;
+    const bool cat = (INF == 1) ? false : (P.C1 != 0);
     int buf = 0;
     wload(0, 0, 0);
     for (int cc = 0; cc < nchunks; ++cc) {
         if (cc) __syncthreads();                     // every wave is done reading the previous halo tile
-        if (MODE == MODE_BF16 && in16) {
+        if constexpr (MODE == MODE_BF16 && INF == 2) {
             // every input tensor is bf16: 16-byte pieces of 8 channels, half the loads / address math / LDS writes, and a
             // plain copy into the bf16 tile when there is no prologue
             constexpr int BP = KT / 8;
             const int total8 = HPX * BP;
             for (int i0 = tid; i0 < total8; i0 += NT * AU) {
-                u32x4 v[AU];
+                // loads only in this loop (nothing consumes a loaded register before every load of the batch is issued: a use here
+                // would put an s_waitcnt vmcnt(0) after each load and serialise the L2 round trips)
+                u32x4 v[AU], v1[AU];
 #pragma unroll
                 for (int u = 0; u < AU; ++u) {
                     const int i = i0 + NT * u;
@@ -185,14 +193,22 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
                     const int pix = (i < total8) ? hp_pix[hp] : -1;
                     const unsigned o0 = (pix >= 0 && c < P.C0) ? (unsigned)(pix * P.C0 + c) * 2u : OOB;
                     v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0);
-                    if (P.C1) {
+                }
+                if (P.C1) {                            // (one uniform branch around the whole second batch, none between loads)
+#pragma unroll
+                    for (int u = 0; u < AU; ++u) {
+                        const int i = i0 + NT * u;
+                        const int hp = i / BP, pc = i % BP;
+                        const int c = cc * KT + pc * 8;
+                        const int pix = (i < total8) ? hp_pix[hp] : -1;
                         const unsigned o1 = (pix >= 0 && c >= P.C0 && c < Cin) ? (unsigned)(pix * P.C1 + (c - P.C0)) * 2u : OOB;
-                        v[u] |= __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
+                        v1[u] = __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < AU; ++u) {
                     const int i = i0 + NT * u;
+                    if (P.C1) v[u] |= v1[u];
                     if (i < total8) {
                         const int hp = i / BP, pc = i % BP;
                         if (P.pro) {
@@ -214,37 +230,48 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
                     }
                 }
             }
-        } else
+        } else {
         for (int i0 = tid; i0 < total; i0 += NT * AU) {
-            u32x4 v[AU];
+            u32x4 v[AU], v1[AU];                       // raw loads first (see above), widened / merged when stored
+            u32x2 h[AU], h1[AU];                       // (bf16 sources: 8 bytes; copying them into v here would already be a use)
 #pragma unroll
             for (int u = 0; u < AU; ++u) {
                 const int i = i0 + NT * u;
                 const int hp = i / APIECES, pc = i % APIECES;
                 const int c = cc * KT + pc * 4;
                 const int pix = (i < total) ? hp_pix[hp] : -1;
-                if (P.x0_bf16) {                       // bf16-stored input (intra-ResnetBlock tensor): 4 channels = 8 bytes
+                if (x0b) {                              // bf16-stored input (intra-ResnetBlock tensor): 4 channels = 8 bytes
                     const unsigned o0 = (pix >= 0 && c < P.C0) ? (unsigned)(pix * P.C0 + c) * 2u : OOB;
-                    const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rs0, o0, 0, 0);
-                    v[u] = u32x4{h2.x << 16, h2.x & 0xFFFF0000u, h2.y << 16, h2.y & 0xFFFF0000u};
+                    h[u] = __builtin_amdgcn_raw_buffer_load_b64(rs0, o0, 0, 0);
                 } else {
                     const unsigned o0 = (pix >= 0 && c < P.C0) ? (unsigned)(pix * P.C0 + c) * 4u : OOB;
                     v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, o0, 0, 0);
                 }
-                if (P.C1) {
-                    if (P.x1_bf16) {
+            }
+            if (cat) {
+#pragma unroll
+                for (int u = 0; u < AU; ++u) {
+                    const int i = i0 + NT * u;
+                    const int hp = i / APIECES, pc = i % APIECES;
+                    const int c = cc * KT + pc * 4;
+                    const int pix = (i < total) ? hp_pix[hp] : -1;
+                    if (x1b) {
                         const unsigned o1 = (pix >= 0 && c >= P.C0 && c < Cin) ? (unsigned)(pix * P.C1 + (c - P.C0)) * 2u : OOB;
-                        const u32x2 h2 = __builtin_amdgcn_raw_buffer_load_b64(rs1, o1, 0, 0);
-                        v[u] |= u32x4{h2.x << 16, h2.x & 0xFFFF0000u, h2.y << 16, h2.y & 0xFFFF0000u};
+                        h1[u] = __builtin_amdgcn_raw_buffer_load_b64(rs1, o1, 0, 0);
                     } else {
                         const unsigned o1 = (pix >= 0 && c >= P.C0 && c < Cin) ? (unsigned)(pix * P.C1 + (c - P.C0)) * 4u : OOB;
-                        v[u] |= __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
+                        v1[u] = __builtin_amdgcn_raw_buffer_load_b128(rs1, o1, 0, 0);
                     }
                 }
             }
 #pragma unroll
             for (int u = 0; u < AU; ++u) {
                 const int i = i0 + NT * u;
+                if (x0b) v[u] = u32x4{h[u].x << 16, h[u].x & 0xFFFF0000u, h[u].y << 16, h[u].y & 0xFFFF0000u};
+                if (cat) {
+                    if (x1b) v[u] |= u32x4{h1[u].x << 16, h1[u].x & 0xFFFF0000u, h1[u].y << 16, h1[u].y & 0xFFFF0000u};
+                    else v[u] |= v1[u];
+                }
                 if (i < total) {
                     const int hp = i / APIECES, pc = i % APIECES;
                     float4 f = make_float4(__uint_as_float(v[u].x), __uint_as_float(v[u].y), __uint_as_float(v[u].z), __uint_as_float(v[u].w));
@@ -259,6 +286,7 @@ __global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
                     M::store4(As + hp * RS, pc * 4, f);
                 }
             }
+        }
         }
         int dy = 0, dx = 0;
         for (int tap = 0; tap < ntaps; ++tap) {
@@ -930,7 +958,6 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     const int BC = a.Cout <= 64 ? 64 : 128;
     // 8-wave workgroups (each wave 32 pixels x 64 channels of the same workgroup tile): 4 waves per SIMD instead of 2;
     // VDX_CONV_NW8=0 selects the 4-wave form (64 x 64 per wave) for comparison
-    static const int nw8 = getenv("VDX_CONV_NW8") ? atoi(getenv("VDX_CONV_NW8")) : 1;
     const int TN = (BC == 64 && a.stride == 2) ? 2 : 4;
     const int BM = 16 * TN * (4 / (BC / 64));
     choose_patch(BM, a.NF, a.F, a.Ho, a.Wo, a.stride, K, a.PH, a.PW, a.NP);
@@ -945,22 +972,32 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
                + (size_t)HPX * ROW_STRIDE + 2 * (size_t)BC * ROW_STRIDE;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((a.NF / a.NP) * a.tiles_y * a.tiles_x, (a.Cout + BC - 1) / BC, a.kind ? 4 : 1);
-#define VDX_LAUNCH_CONV(MODE_, BC_, TN_)                                                                 \
+    const bool in16 = mode == MODE_BF16 && a.x0_bf16 && (!a.C1 || a.x1_bf16) && (a.C0 % 8 == 0) && (a.C1 % 8 == 0);
+    const int inf = in16 ? 2 : (!a.x0_bf16 && !(a.C1 && a.x1_bf16)) ? 0 : (mode == MODE_BF16 && a.x0_bf16 && !a.C1) ? 1 : 3;
+#define VDX_LAUNCH_CONV_K(KFN_, NTH_)                                                                    \
     do {                                                                                                  \
-        const bool w8 = nw8 && TN_ == 4;                                                                  \
-        auto kfn = w8 ? conv_igemm_kernel<MODE_, BC_, 2, 8> : conv_igemm_kernel<MODE_, BC_, TN_, 4>;      \
+        auto kfn = KFN_;                                                                                  \
         if (lds > 64 * 1024) {                                                                            \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
             if (e != hipSuccess) return e;                                                                \
         }                                                                                                 \
-        hipLaunchKernelGGL(kfn, grid, dim3(w8 ? 512 : 256), lds, st, a);                                             \
+        hipLaunchKernelGGL(kfn, grid, dim3(NTH_), lds, st, a);                                            \
+    } while (0)
+    // 64-pixel-per-wave shapes run as 8 waves x 32 pixels (measured better than 4 waves x 64 pixels); stride-2 64-channel tiles as 4 x 32
+#define VDX_LAUNCH_CONV_T(MODE_, INF_)                                                                   \
+    do {                                                                                                  \
+        if (BC == 128) VDX_LAUNCH_CONV_K((conv_igemm_kernel<MODE_, 128, 2, 8, INF_>), 512);              \
+        else if (TN == 4) VDX_LAUNCH_CONV_K((conv_igemm_kernel<MODE_, 64, 2, 8, INF_>), 512);            \
+        else VDX_LAUNCH_CONV_K((conv_igemm_kernel<MODE_, 64, 2, 4, INF_>), 256);                          \
     } while (0)
     if (mode == MODE_F32) {
-        if (BC == 128) VDX_LAUNCH_CONV(MODE_F32, 128, 4); else if (TN == 4) VDX_LAUNCH_CONV(MODE_F32, 64, 4); else VDX_LAUNCH_CONV(MODE_F32, 64, 2);
+        if (inf == 0) VDX_LAUNCH_CONV_T(MODE_F32, 0); else VDX_LAUNCH_CONV_T(MODE_F32, 3);
     } else {
-        if (BC == 128) VDX_LAUNCH_CONV(MODE_BF16, 128, 4); else if (TN == 4) VDX_LAUNCH_CONV(MODE_BF16, 64, 4); else VDX_LAUNCH_CONV(MODE_BF16, 64, 2);
+        if (inf == 0) VDX_LAUNCH_CONV_T(MODE_BF16, 0); else if (inf == 1) VDX_LAUNCH_CONV_T(MODE_BF16, 1);
+        else if (inf == 2) VDX_LAUNCH_CONV_T(MODE_BF16, 2); else VDX_LAUNCH_CONV_T(MODE_BF16, 3);
     }
-#undef VDX_LAUNCH_CONV
+#undef VDX_LAUNCH_CONV_T
+#undef VDX_LAUNCH_CONV_K
     return hipGetLastError();
 }
 
