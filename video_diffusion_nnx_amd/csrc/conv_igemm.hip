@@ -31,7 +31,7 @@ constexpr unsigned OOB = 0xFFFFFFF0u;      // buffer-load offset beyond num_reco
 // format branch between them: 0 = fp32 (x0 and x1), 1 = bf16 x0 without concat, 2 = every input bf16 with channel counts that
 // are multiples of 8 (16-byte pieces), 3 = anything else (formats read from the descriptor at run time).
 template <int MODE, int BC, int TN, int NW, int INF>
-__global__ __launch_bounds__(64 * NW) void conv_igemm_kernel(const ConvArgs P) {
+__global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_igemm_kernel(const ConvArgs P) {
     using M = Mma<MODE>;
     constexpr int KT = M::KT;
     constexpr int RS = ROW_STRIDE;
