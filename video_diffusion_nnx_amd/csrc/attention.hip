@@ -631,7 +631,7 @@ static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
 // global memory / L2 (each x row is read by the 8 head-workgroups), weight fragments from LDS, and the core runs in registers as in
 // attention_reg_kernel.  Output: O[row][head*32 + d] bf16; the out-projection (+bias, +residual) is a plain 1x1 conv_igemm.
 template <bool IO16, int TT>
-__global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, const int seq_per_block) {
+__global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, const int seq_per_block, const int nchunks) {
     // TT sequences per wave at a time: each weight fragment read from LDS feeds TT MFMAs (one sequence per read would make the kernel
     // LDS-bandwidth bound: 6 KB of fragments per 6 MFMAs per wave), and the x fragments run through a 4-deep register ring so that
     // global loads are issued four K steps ahead of their use.
@@ -640,7 +640,10 @@ __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, c
     extern __shared__ __attribute__((aligned(16))) char smem[];      // W_h [96 rows][C * 2 + 32]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lp = lane & 15, q = lane >> 4;
-    const int h = blockIdx.x, HD = P.heads * D;
+    // XCD-aware decode (see sla_head_kernel): the 8 heads of one sequence chunk share an XCD and its L2
+    const int h = (blockIdx.x >> 3) & 7, HD = P.heads * D;
+    const int chunk_id = (blockIdx.x >> 6) * 8 + (blockIdx.x & 7);
+    if (chunk_id >= nchunks) return;                                  // (uniform)
     const int RSW = P.C * 2 + 32;                                     // +32: conflict-free ds_read_b128 over 16 rows
     const int cpr = P.C / 8;                                          // 16-byte pieces per weight row
     for (int i = tid; i < 96 * cpr; i += 512) {
@@ -660,7 +663,7 @@ __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, c
     const float escale = P.scale * 1.44269504088896f;
     const bool masked = P.L < 16;
     __syncthreads();
-    const int s0 = blockIdx.y * seq_per_block;
+    const int s0 = chunk_id * seq_per_block;
     const int send = min((int)P.nseq, s0 + seq_per_block);
     const int nkt = P.C / 32;                                         // multiple of 4 (launcher)
     const char* wrow = smem + lp * RSW + q * 16;
@@ -771,7 +774,7 @@ hipError_t launch_attention_heads(AttnArgs a, hipStream_t st) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kfn, dim3(a.heads, (unsigned)chunks), dim3(512), lds, st, a, (int)spb);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)((chunks + 7) / 8 * 64)), dim3(512), lds, st, a, (int)spb, (int)chunks);
         return hipGetLastError();
     };
     return a.io_bf16 ? go(attention_head_kernel<true, TT>) : go(attention_head_kernel<false, TT>);

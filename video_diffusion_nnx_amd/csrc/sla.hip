@@ -682,14 +682,19 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
 // the pixel index with the accumulators as operands; the 32x32 context stays in registers.  Phase 2 walks the pixels again (x is hot
 // in L2): q projection, softmax over D, out = ctx^T q -> O[row][head*32 + e] bf16.  to_out (+ residual) is a plain 1x1 conv_igemm.
 template <bool IO16, int TT>
-__global__ __launch_bounds__(512) void sla_head_kernel(const SlaArgs P, void* __restrict__ O, const int frames_per_block) {
+__global__ __launch_bounds__(512) void sla_head_kernel(const SlaArgs P, void* __restrict__ O, const int frames_per_block, const int nchunks) {
     using M = Mma<MODE_BF16>;
     constexpr int D = 32;
     constexpr float L2E = 1.44269504088896f;
     extern __shared__ __attribute__((aligned(16))) char smem[];      // W_h [q 32 | k 32 | v 32 rows][C * 2 + 32]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lp = lane & 15, q = lane >> 4;
-    const int h = blockIdx.x, HD = P.heads * D;
+    // XCD-aware decode: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so ids {c, c + 8, ..., c + 56}
+    // of one group of 64 -- the 8 heads of ONE frame chunk -- land on the same XCD at about the same time and x comes from HBM once
+    // instead of once per head
+    const int h = (blockIdx.x >> 3) & 7, HD = P.heads * D;
+    const int chunk_id = (blockIdx.x >> 6) * 8 + (blockIdx.x & 7);
+    if (chunk_id >= nchunks) return;                                  // (uniform)
     const int RSW = P.C * 2 + 32;
     const int cpr = P.C / 8;
     for (int i = tid; i < 96 * cpr; i += 512) {
@@ -702,13 +707,13 @@ __global__ __launch_bounds__(512) void sla_head_kernel(const SlaArgs P, void* __
     __syncthreads();
     const int nkt = P.C / 32;
     const char* wrow = smem + lp * RSW + q * 16;
-    const int n_end = min(P.NF, (int)(blockIdx.y + 1) * frames_per_block);
+    const int n_end = min(P.NF, (chunk_id + 1) * frames_per_block);
     auto xload = [&](size_t e) -> uint4 {                              // 8 consecutive channels at element offset e as bf16
         if (IO16) return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.x) + e * 2);
         const float4 a = *reinterpret_cast<const float4*>(P.x + e), b = *reinterpret_cast<const float4*>(P.x + e + 4);
         return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
     };
-    for (int n = blockIdx.y * frames_per_block + w; n < n_end; n += 8) {
+    for (int n = chunk_id * frames_per_block + w; n < n_end; n += 8) {
         const size_t xbase = (size_t)n * P.N * P.C + (size_t)lp * P.C + 8 * q;     // token lp of the frame, channel group q
         // x fragments run through a 4-deep register ring: global loads are issued four K steps ahead of their use.  The walk is
         // pixels 0..N (phase 1) and then 0..N again (phase 2), so the ring simply wraps once.
@@ -849,7 +854,7 @@ hipError_t launch_sla_heads(SlaArgs a, void* O, hipStream_t st) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kfn, dim3(a.heads, (unsigned)chunks), dim3(512), lds, st, a, O, (int)fpb);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)((chunks + 7) / 8 * 64)), dim3(512), lds, st, a, O, (int)fpb, (int)chunks);
         return hipGetLastError();
     };
     if (a.N % 64 == 0) return a.io_bf16 ? go(sla_head_kernel<true, 4>) : go(sla_head_kernel<false, 4>);
