@@ -619,7 +619,7 @@ static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
 
 // ---- persistent 3x3 conv with Cin = 128 (two-pointer concat of 64 + 64, or one 128-channel tensor), Cout = 64, bf16 inputs ----
 // Same scheme as conv64p_kernel, but a workgroup owns HALF of the output channels (32 x 128 x 9 bf16 weights = 72 KB resident);
-// workgroups 2r and 2r+1 walk the same tile range, so the second reader of a tile finds it in L2.  The 128-channel halo tile
+// two workgroups on the same XCD walk the same tile range, so the second reader of a tile finds it in L2.  The 128-channel halo tile
 // (two 64-channel planes, 81 KB) is single-buffered: the next tile is fetched into registers during the MFMAs and written
 // after them.  No prologue (these are the first convs of ResnetBlocks whose input is a concat).
 constexpr int C128_WPL = 9 * 32 * 128;                // bytes per weight plane [9 taps x 32 rows][128 B]
@@ -636,9 +636,13 @@ __global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, cons
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lp = lane & 15, q = lane >> 4;
-    const int half = blockIdx.x & 1, co0 = half * 32;
+    // workgroup ids are dealt round-robin to the 8 XCDs: ids i and i + 8 (same XCD, same L2, dispatched together) are the two
+    // channel halves of one tile range, so the second reader of a tile finds it in L2 (ids 2r / 2r + 1 sit on different XCDs
+    // and both fetched every tile from HBM: 1.49 GB per launch measured against 0.81 GB algorithmic)
+    const int half = (blockIdx.x >> 3) & 1, co0 = half * 32;
+    const int range = (blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
     const int tiles_x = P.W >> 4, tiles_pf = tiles_x * (P.H >> 4);
-    const int t0 = (blockIdx.x >> 1) * tiles_per_block, t1 = min(t0 + tiles_per_block, total_tiles);
+    const int t0 = range * tiles_per_block, t1 = min(t0 + tiles_per_block, total_tiles);
     if (t0 >= t1) return;
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x0), 0, P.x0_bytes, 0x00020000);
@@ -779,7 +783,7 @@ static hipError_t launch_conv128x64p(const ConvArgs& a, hipStream_t st) {
     auto kfn = conv128x64p_kernel;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kfn, dim3(2 * nranges), dim3(512), lds, st, a, tpb, total);
+    hipLaunchKernelGGL(kfn, dim3((nranges + 7) / 8 * 16), dim3(512), lds, st, a, tpb, total);
     return hipGetLastError();
 }
 
