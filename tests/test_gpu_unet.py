@@ -33,6 +33,7 @@ def _build(kw, mode, seed=5):
     (dict(dim=16, channels=3), (2, 3, 4, 16, 16)),
     (dict(dim=32, channels=1), (1, 1, 10, 32, 32)),                      # YAML-like: F = 10 (padded attention)
     (dict(dim=16, channels=1, dim_mults=(1, 2), use_sparse_linear_attn=False), (1, 1, 3, 8, 8)),
+    (dict(dim=64, channels=1), (3, 1, 5, 32, 32)),                       # C = 256 / 512 levels with ragged sequence groups (per-head kernels)
 ])
 def test_unet_forward_parity(mode, kw, shape):
     cfg, p, m = _build(kw, mode)
@@ -114,6 +115,7 @@ TOL_ACT16 = 3e-2
     (dict(dim=16, channels=3), (2, 3, 4, 16, 16)),
     (dict(dim=32, channels=1), (1, 1, 10, 32, 32)),
     (dict(dim=16, channels=1, dim_mults=(1, 2), use_sparse_linear_attn=False), (1, 1, 3, 8, 8)),
+    (dict(dim=64, channels=1), (3, 1, 5, 32, 32)),                       # C = 256 / 512 levels with ragged sequence groups (per-head kernels)
 ])
 def test_unet_forward_bf16_storage(kw, shape):
     cfg, p, m = _build(kw, 'bf16')

@@ -255,9 +255,19 @@ __global__ __launch_bounds__(256) void init_conv_mfma_kernel(const float* __rest
     }
     for (int i = tid; i < 64 * RSK / 4; i += 256) reinterpret_cast<unsigned*>(wl)[i] = 0u;
     __syncthreads();
-    for (int i = tid; i < K * K * Cout; i += 256) {           // Flax (kh, kw, 1, Cout)
-        const int co = i % Cout, t = i / Cout;
-        if (co < 64) M::store1(wl + co * RSK, (t / K) * 8 + (t % K), w[i]);
+    {   // Flax (kh, kw, 1, Cout): <= 4096 weights, all of a thread's loads issued before the first LDS store
+        float wr[16];
+        const int nw = K * K * Cout;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int i = tid + u * 256; wr[u] = w[i < nw ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + u * 256;
+            if (i < nw) {
+                const int co = i % Cout, t = i / Cout;
+                if (co < 64) M::store1(wl + co * RSK, (t / K) * 8 + (t % K), wr[u]);
+            }
+        }
     }
     {   // this thread's pixel row of the im2col matrix
         const int py = tid >> 4, px = tid & 15;
@@ -288,6 +298,29 @@ __global__ __launch_bounds__(256) void init_conv_mfma_kernel(const float* __rest
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
+    }
+    if (y_bf16 && Cout == 64) {
+        // bf16 output: meet in LDS ([pixel][64 channels] = 128-byte rows over the im2col buffer) so that the global stores are
+        // 16 bytes per lane and a tile row of 16 pixels is one contiguous 2 KB run (the accumulator layout would write 32-byte runs)
+        __syncthreads();                                       // every wave is done reading col
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                const float4 bi = *reinterpret_cast<const float4*>(bias + tm * 16 + 4 * q);
+                *reinterpret_cast<uint2*>(col + ((wv * 4 + tn) * 16 + lp) * RSK + (tm * 16 + 4 * q) * 2) =
+                    make_uint2(pack_bf16x2(acc[tm][tn][0] + bi.x, acc[tm][tn][1] + bi.y), pack_bf16x2(acc[tm][tn][2] + bi.z, acc[tm][tn][3] + bi.w));
+            }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = tid + u * 256, p = i >> 3, pc = i & 7;
+            const int oy = ty * 16 + (p >> 4), ox = tx * 16 + (p & 15);
+            if (oy < H && ox < W)
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y) + (((((size_t)b * F + f) * H + oy) * W + ox) * 64) * 2 + pc * 16) =
+                    *reinterpret_cast<const uint4*>(col + p * RSK + pc * 16);
+        }
+        return;
     }
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
@@ -355,7 +388,57 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
     }
 }
 
+// bf16 input whose D channels are one 8-channel piece per lane of a pixel's lane group (D = 8 * lpp): the lane's weights live in
+// registers and four pixels are in flight per lane group (the generic form has one 16-byte load in flight per lane and re-reads
+// its weights from L1 for every pixel)
+template <int COUT>
+__global__ __launch_bounds__(256) void final_conv16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, long npix, int D, int lpp) {
+    constexpr int U = 4;
+    const int sub = threadIdx.x % lpp, pl = threadIdx.x / lpp, ppb = 256 / lpp;
+    float wr[COUT][8], br[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        br[co] = bias[co];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[co][k] = w[(size_t)(sub * 8 + k) * COUT + co];
+    }
+    for (long g0 = (long)blockIdx.x * U; g0 * ppb < npix; g0 += (long)gridDim.x * U) {
+        uint4 raw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pix = (g0 + u) * ppb + pl;
+            raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(x) + ((size_t)(pix < npix ? pix : 0) * D + sub * 8) * 2);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pix = (g0 + u) * ppb + pl;
+            float v[8];
+            unpack8(raw[u], v);
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s = fmaf(v[k], wr[co][k], s);
+                for (int o = 1; o < lpp; o <<= 1) s += __shfl_xor(s, o);
+                if (sub == 0 && pix < npix) y[(size_t)pix * COUT + co] = s + br[co];
+            }
+        }
+    }
+}
+
 hipError_t launch_final_conv(const float* x, const float* w, const float* bias, float* y, long npix, int D, int Cout, int x_bf16, hipStream_t st) {
+    if (x_bf16 && D % 8 == 0 && D <= 128 && ((D / 8) & (D / 8 - 1)) == 0 && Cout >= 1 && Cout <= 4) {
+        const int lpp = D / 8, ppb = 256 / lpp;
+        const int blocks = (int)std::min<long>((npix + 4L * ppb - 1) / (4L * ppb), 4096);
+        switch (Cout) {
+            case 1: hipLaunchKernelGGL(final_conv16_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, lpp); break;
+            case 2: hipLaunchKernelGGL(final_conv16_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, lpp); break;
+            case 3: hipLaunchKernelGGL(final_conv16_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, lpp); break;
+            default: hipLaunchKernelGGL(final_conv16_kernel<4>, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, lpp); break;
+        }
+        return hipGetLastError();
+    }
     const int per = (x_bf16 && D % 8 == 0) ? 8 : 4;       // channels per lane and pass
     if (per == 4) x_bf16 = x_bf16 ? -1 : 0;
     if (x_bf16 < 0) return hipErrorInvalidValue;          // bf16 tensors have D % 8 == 0 (config check)
