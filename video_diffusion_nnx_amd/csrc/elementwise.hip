@@ -6,6 +6,7 @@
 //   time_mlp ........... SinusoidalPosEmb -> Linear -> GELU(tanh) -> Linear (+ cond mix)   modules.py:30-45, unet3d.py:128-133,288-298
 //   resblock_ss ........ LayerNorm(Linear(SiLU(t)))  for every ResnetBlock in one launch    modules.py:202-208,233-238
 #include "vdx_common.h"
+#include <stdlib.h>
 #include "vdx_internal.h"
 
 namespace vdx {
@@ -155,7 +156,11 @@ hipError_t launch_resblock_tail(TailArgs a, hipStream_t st) {
         a.lpp = lpp;
         const int vpl = (octs + lpp - 1) / lpp;
         const int ppb = 256 / lpp;
-        const int gx = (int)std::min<long>((a.pix_per_sample + ppb - 1) / ppb, 2048);
+        // every workgroup starts with the statistics -> coefficient chain (a few dependent L2 round trips): give it at least
+        // ~8 pixel passes of work when the launch has enough workgroups to fill the chip anyway
+        static const int tail_wgs = getenv("VDX_TAIL_WGS") ? atoi(getenv("VDX_TAIL_WGS")) : 8192;
+        const long need = (a.pix_per_sample + ppb - 1) / ppb;
+        const int gx = (int)std::min<long>(need, std::max<long>(1, std::min<long>(2048, tail_wgs / std::max(1, a.batch))));
         dim3 grid(gx, a.batch);
         switch (vpl) {
             case 1: hipLaunchKernelGGL(resblock_tail16_kernel<1>, grid, dim3(256), 0, st, a); break;
@@ -170,7 +175,8 @@ hipError_t launch_resblock_tail(TailArgs a, hipStream_t st) {
     a.lpp = lpp;
     const int vpl = (quads + lpp - 1) / lpp;
     const int ppb = 256 / lpp;
-    int gx = (int)std::min<long>((a.pix_per_sample + ppb - 1) / ppb, 2048);
+    static const int tail_wgs32 = getenv("VDX_TAIL_WGS") ? atoi(getenv("VDX_TAIL_WGS")) : 8192;
+    int gx = (int)std::min<long>((a.pix_per_sample + ppb - 1) / ppb, std::max<long>(1, std::min<long>(2048, tail_wgs32 / std::max(1, a.batch))));
     dim3 grid(gx, a.batch);
     switch (vpl) {
         case 1: hipLaunchKernelGGL(resblock_tail_kernel<1>, grid, dim3(256), 0, st, a); break;

@@ -9,6 +9,7 @@
 //   apply     dy = rstd_g * (k * dz - S1 - xh * S2) ;  LN: dr = rstd_p * (g*dout - mean_c(g*dout) - rh * mean_c(g*dout*rh))
 // (jax.value_and_grad of the same expressions, reference trainer.py:361.)
 #include "vdx_common.h"
+#include <stdlib.h>
 #include "vdx_internal.h"
 
 namespace vdx {
@@ -235,7 +236,10 @@ hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st) {
     const int vpl = (quads + lpp - 1) / lpp;
     const int ppb = 256 / lpp;
     // few, fat workgroups: every workgroup ends in 2..4 atomics per channel onto the same [B][C] rows (contention-bound beyond ~64)
-    const int gx = (int)std::max<long>(1, std::min<long>((a.pix_per_sample + ppb - 1) / ppb, 48));
+    // the reduce pass is a latency-bound stream (one pixel group in flight per lane group): enough workgroups to give every
+    // SIMD several waves, few enough that the per-workgroup table build and the 2C..4C atomics of the flush stay small
+    static const int red_wgs = getenv("VDX_NORMBWD_WGS") ? atoi(getenv("VDX_NORMBWD_WGS")) : 192;
+    const int gx = (int)std::max<long>(1, std::min<long>((a.pix_per_sample + ppb - 1) / ppb, std::max(1, red_wgs / std::max(1, a.batch))));
     hipError_t e = hipMemsetAsync(a.R, 0, (size_t)a.batch * a.C * 2 * 4, st);
     if (e != hipSuccess) return e;
     dim3 grid(gx, a.batch);
