@@ -92,12 +92,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
     }
     if (P.pro) {
         // per-channel affine of GroupNorm-apply (+ time scale/shift):  x_hat = x * a + d
-        if (tid < P.groups) {
-            const double cnt = (double)P.F * P.H * P.W * (Cin / P.groups);
-            float m, rs;
-            gn_mean_rstd(P.in_stats, b, tid, P.groups, cnt, m, rs);
-            gmean[2 * tid] = m; gmean[2 * tid + 1] = rs;
-        }
+        gn_mean_rstd_wg(P.in_stats, b, P.groups, (double)P.F * P.H * P.W * (Cin / P.groups), gmean, tid, NT);
         __syncthreads();
         for (int c = tid; c < P.CinPad; c += NT) {
             float a = 0.f, d = 0.f;
@@ -174,9 +169,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
     const bool cat = (INF == 1) ? false : (P.C1 != 0);
     int buf = 0;
     wload(0, 0, 0);
-    for (int cc = 0; cc < ((P.dbg & 16) ? 0 : nchunks); ++cc) {
+    for (int cc = 0; cc < nchunks; ++cc) {
         if (cc) __syncthreads();                     // every wave is done reading the previous halo tile
-        if (!((P.dbg & 4) && cc)) {
         if constexpr (MODE == MODE_BF16 && INF == 2) {
             // every input tensor is bf16: 16-byte pieces of 8 channels, half the loads / address math / LDS writes, and a
             // plain copy into the bf16 tile when there is no prologue
@@ -289,15 +283,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
             }
         }
         }
-        }
         int dy = 0, dx = 0;
         for (int tap = 0; tap < ntaps; ++tap) {
-            if (!((P.dbg & 1) && (cc | tap))) wstore(buf);
-            if (!((P.dbg & 2) && tap)) __syncthreads();
+            wstore(buf);
+            __syncthreads();
             int ndy = dy, ndx = dx + 1, ncc = cc;
             if (ndx == KW) { ndx = 0; ndy = dy + 1; }
             if (ndy == KH) { ndy = 0; ncc = cc + 1; }
-            if (ncc < nchunks && !(P.dbg & 1)) wload(ndy, ndx, ncc);      // prefetch the next weight tile while this one is consumed
+            if (ncc < nchunks) wload(ndy, ndx, ncc);      // prefetch the next weight tile while this one is consumed
             const int tapoff = (dy * IW + dx) * RS;
             const char* wt = Ws + buf * (BC * RS) + (wc * 64 + lp) * RS + q * 16;
 #pragma unroll
@@ -310,7 +303,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
-                    for (int tn = 0; tn < TN; ++tn) { if (P.dbg & 8) acc[tm][tn][0] += __uint_as_float(af[tm].x ^ bf[tn].x); else M::mma(acc[tm][tn], af[tm], bf[tn]); }
+                    for (int tn = 0; tn < TN; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
             }
             dy = ndy; dx = ndx;
             buf ^= 1;
@@ -333,7 +326,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
             float4 v;
             v.x = acc[tm][tn][0] + bias.x; v.y = acc[tm][tn][1] + bias.y;
             v.z = acc[tm][tn][2] + bias.z; v.w = acc[tm][tn][3] + bias.w;
-            if (cvalid && gout[tn] >= 0 && !(P.dbg & 64)) {
+            if (cvalid && gout[tn] >= 0) {
                 if (P.res) {
                     const float4 r4 = load4_f32_or_bf16(P.res, (size_t)gout[tn] * P.Cout + co, P.res_bf16);
                     v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
@@ -344,7 +337,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
                 ss.x += v.x * v.x; ss.y += v.y * v.y; ss.z += v.z * v.z; ss.w += v.w * v.w;
             }
         }
-        if (P.out_stats && !(P.dbg & 32) && grp4) {
+        if (P.out_stats && grp4) {
             // a lane's 4 channels belong to one group (channels per group % 4 == 0): sum them in the lane first, then ONE pair of
             // 16-lane reductions and LDS atomics per channel tile instead of four, straight into the group's slot
             const float s4 = reduce16((s.x + s.y) + (s.z + s.w)), q4 = reduce16((ss.x + ss.y) + (ss.z + ss.w));
@@ -352,7 +345,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
                 const int gl = co / st_cpg - st_glo;
                 atomicAdd(&chs[gl], s4); atomicAdd(&chs[BC + gl], q4);
             }
-        } else if (P.out_stats && !(P.dbg & 32)) {
+        } else if (P.out_stats) {
             s.x = reduce16(s.x); s.y = reduce16(s.y); s.z = reduce16(s.z); s.w = reduce16(s.w);
             ss.x = reduce16(ss.x); ss.y = reduce16(ss.y); ss.z = reduce16(ss.z); ss.w = reduce16(ss.w);
             if (lp == 0) {
@@ -364,7 +357,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
             }
         }
     }
-    if (P.out_stats && !(P.dbg & 32)) {
+    if (P.out_stats) {
         __syncthreads();
         const int cpg = P.Cout / P.out_groups;               // channels per group
         const int g_lo = c0 / cpg;
@@ -486,11 +479,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     // GroupNorm-apply coefficients of sample b (all threads call; ends with a barrier)
     auto make_coef = [&](int b) {
         if (!PRO) return;
-        if (tid < P.groups) {
-            float m, rsd;
-            gn_mean_rstd(P.in_stats, b, tid, P.groups, (double)P.F * P.H * P.W * (64 / P.groups), m, rsd);
-            gmean[2 * tid] = m; gmean[2 * tid + 1] = rsd;
-        }
+        gn_mean_rstd_wg(P.in_stats, b, P.groups, (double)P.F * P.H * P.W * (64 / P.groups), gmean, tid, 512);
         __syncthreads();
         if (tid < 64) {
             const int g = tid / (64 / P.groups);
@@ -973,8 +962,6 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
             return launch_conv128x64p(a, st);
     }
     // variant: 64-channel tiles take 256 pixels per workgroup (stride 1) so every wave owns a 64x64 tile
-    static const int conv_dbg = getenv("VDX_CONV_DBG") ? atoi(getenv("VDX_CONV_DBG")) : 0;
-    a.dbg = conv_dbg;
     const int BC = a.Cout <= 64 ? 64 : 128;
     // 8-wave workgroups (each wave 32 pixels x 64 channels of the same workgroup tile): 4 waves per SIMD instead of 2;
     // VDX_CONV_NW8=0 selects the 4-wave form (64 x 64 per wave) for comparison

@@ -22,11 +22,7 @@ __global__ __launch_bounds__(256) void resblock_tail_kernel(TailArgs P) {
     const int C = P.C;
     // a workgroup never spans samples: blockIdx.y = sample
     const int b = blockIdx.y;
-    if (tid < P.groups) {
-        float m, rs;
-        gn_mean_rstd(P.stats, b, tid, P.groups, (double)P.pix_per_sample * (C / P.groups), m, rs);
-        gm[2 * tid] = m; gm[2 * tid + 1] = rs;
-    }
+    gn_mean_rstd_wg(P.stats, b, P.groups, (double)P.pix_per_sample * (C / P.groups), gm, tid, 256);
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         const int g = c / (C / P.groups);
@@ -93,11 +89,7 @@ __global__ __launch_bounds__(256) void resblock_tail16_kernel(TailArgs P) {
     const int tid = threadIdx.x;
     const int C = P.C;
     const int b = blockIdx.y;
-    if (tid < P.groups) {
-        float m, rs;
-        gn_mean_rstd(P.stats, b, tid, P.groups, (double)P.pix_per_sample * (C / P.groups), m, rs);
-        gm[2 * tid] = m; gm[2 * tid + 1] = rs;
-    }
+    gn_mean_rstd_wg(P.stats, b, P.groups, (double)P.pix_per_sample * (C / P.groups), gm, tid, 256);
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         const int g = c / (C / P.groups);

@@ -24,11 +24,7 @@ struct NbTables { float* mu; float* rs; float* a; float* d; };
 
 __device__ __forceinline__ void nb_build_tables(const NormBwdArgs& P, int b, float* gm, NbTables T) {
     const int tid = threadIdx.x, C = P.C;
-    if (tid < P.groups) {
-        float m, rs;
-        gn_mean_rstd(P.stats, b, tid, P.groups, (double)P.pix_per_sample * (C / P.groups), m, rs);
-        gm[2 * tid] = m; gm[2 * tid + 1] = rs;
-    }
+    gn_mean_rstd_wg(P.stats, b, P.groups, (double)P.pix_per_sample * (C / P.groups), gm, tid, 256);
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         const int g = c / (C / P.groups);

@@ -179,6 +179,27 @@ __device__ __forceinline__ void gn_mean_rstd(const double* stats, int b, int g, 
     rstd = (float)(1.0 / sqrt(var + (double)NORM_EPS));
 }
 
+// Workgroup form: thread t loads slot (t & 31) of group (t >> 5) -- every slot of every group in ONE batch of loads -- and the 32
+// lanes of a group reduce with shuffles (a fixed tree, so the result does not depend on timing).  Writes gm[2g] = mean,
+// gm[2g+1] = rstd (LDS); the caller synchronises.  nthreads is a multiple of 64.
+__device__ __forceinline__ void gn_mean_rstd_wg(const double* stats, int b, int groups, double count, float* gm, int tid, int nthreads) {
+    static_assert(GN_SLOTS == 32, "GN_SLOTS");
+    for (int t = tid; t < groups * GN_SLOTS; t += nthreads) {
+        const int g = t >> 5, slot = t & 31;
+        const double2 v = *reinterpret_cast<const double2*>(stats + (((size_t)b * GN_SLOTS + slot) * groups + g) * 2);
+        double s = v.x, ss = v.y;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+        if (slot == 0) {
+            const double m = s / count;
+            double var = ss / count - m * m;     // fast variance, as Flax (use_fast_variance=True)
+            if (var < 0.0) var = 0.0;
+            gm[2 * g] = (float)m;
+            gm[2 * g + 1] = (float)(1.0 / sqrt(var + (double)NORM_EPS));
+        }
+    }
+}
+
 }  // namespace vdx
 
 #define VDX_CHECK_HIP(expr)                                                      \

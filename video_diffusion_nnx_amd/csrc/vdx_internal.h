@@ -31,7 +31,6 @@ struct ConvArgs {
     int x1_bf16;                    // x1 stored as bf16 (bf16 activation storage)
     const float* res;               // optional residual added to the output: y = conv + bias + res  ([.., Cout] like y)
     int res_bf16;                   // res stored as bf16
-    int dbg;                        // VDX_CONV_DBG (timing diagnostics only, results are WRONG when non-zero): 1 no weight reloads, 2 no per-tap barrier, 4 no halo restaging, 8 no MFMA
     int wrows, wrow0;               // packed weight rows per tap / first row (0,0 = Cout rows from 0): slices a wider packing
     // completed by launch_conv
     int Ho, Wo, Hy, Wy, CinPad, PH, PW, NP, tiles_y, tiles_x;

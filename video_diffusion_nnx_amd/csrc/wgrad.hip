@@ -69,11 +69,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
         const int b = f / P.F;
         __syncthreads();                                      // previous patch fully consumed
         if (P.pro && b != last_b) {                           // per-sample prologue coefficients for this channel tile
-            if (tid < P.groups) {
-                float m, rs;
-                gn_mean_rstd(P.in_stats, b, tid, P.groups, (double)P.F * P.H * P.W * (Cin / P.groups), m, rs);
-                gm[2 * tid] = m; gm[2 * tid + 1] = rs;
-            }
+            gn_mean_rstd_wg(P.in_stats, b, P.groups, (double)P.F * P.H * P.W * (Cin / P.groups), gm, tid, 256);
             __syncthreads();
             if (tid < 64) {
                 const int c = ci0 + tid;
@@ -304,11 +300,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel
         const int b = (int)(pid / patches_per_frame) / P.F;
         __syncthreads();                                      // previous patch fully consumed
         if (P.pro && b != last_b) {
-            if (tid < P.groups) {
-                float m, rs;
-                gn_mean_rstd(P.in_stats, b, tid, P.groups, (double)P.F * P.H * P.W * (Cin / P.groups), m, rs);
-                gm[2 * tid] = m; gm[2 * tid + 1] = rs;
-            }
+            gn_mean_rstd_wg(P.in_stats, b, P.groups, (double)P.F * P.H * P.W * (Cin / P.groups), gm, tid, NTH);
             __syncthreads();
             if (tid < 64) {
                 const int c = ci0 + tid;
