@@ -105,6 +105,7 @@ ATTN_CASES = [
     (2, 4, 2, 2, 128, 8, False),      # 4 tokens
     (1, 2, 4, 4, 256, 8, False),
     (1, 2, 5, 5, 64, 8, False),       # 25 tokens -> LP 32
+    (1, 16, 192, 192, 64, 8, True),   # 36864 sequences: workgroups walk 9 sub-tiles (more than 8, last workgroup ragged)
 ]
 
 

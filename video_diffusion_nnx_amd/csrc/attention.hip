@@ -619,7 +619,10 @@ static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     const long subtiles = (a.nseq + 3) / 4;
-    const int nsub = (int)std::min<long>(8, std::max<long>(1, subtiles / 1024));
+    // sub-tiles per workgroup: the per-head weight fragments (12 KB per wave) are loaded once per workgroup, so fatter workgroups
+    // amortise them as long as ~1024 workgroups remain to fill the chip
+    static const int nsub_cap = getenv("VDX_ATTN_NSUB") ? atoi(getenv("VDX_ATTN_NSUB")) : 32;
+    const int nsub = (int)std::min<long>(nsub_cap, std::max<long>(1, subtiles / 1024));
     const long blocks = (subtiles + nsub - 1) / nsub;
     hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, st, a, nsub);
     return hipGetLastError();

@@ -922,7 +922,8 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
     // traffic (8 x 4.4 KB per chunk, written here and re-read by the combine) per doubling
     {
         const int tiles = (a.N + 63) / 64;
-        while (a.nsub * 2 <= tiles && (long)a.NF * ((tiles + 2 * a.nsub - 1) / (2 * a.nsub)) >= 1024) a.nsub *= 2;
+        static const long min_wgs = getenv("VDX_SLA_MINWG") ? atol(getenv("VDX_SLA_MINWG")) : 1024;
+        while (a.nsub * 2 <= tiles && (long)a.NF * ((tiles + 2 * a.nsub - 1) / (2 * a.nsub)) >= min_wgs) a.nsub *= 2;
         a.nchunk = (tiles + a.nsub - 1) / a.nsub;
     }
     const size_t part_bytes = (((size_t)a.NF * a.nchunk * a.heads * SLA_PART * 4) + 255) / 256 * 256;
