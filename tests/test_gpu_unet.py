@@ -168,3 +168,20 @@ def test_north_star_shape_bf16_storage():
     assert _rel(m(x, t).cpu().double(), ref) < TOL_ACT16
     m.act_bf16 = False                                   # fp32 storage at the same batch: conv64p with fp32 / bf16 inputs mixed
     assert _rel(m(x, t).cpu().double(), ref) < TOL['bf16']
+
+
+def test_north_star_shape_bf16_storage_batch8():
+    """B = 8: the tail kernels are capped at 8192 workgroups, so at this batch every workgroup of the level-0 tails walks two pixel
+    passes (the multi-pass loop of resblock_tail16_kernel), and the weight-resident kernels walk longer tile ranges."""
+    kw = dict(dim=64, channels=1)
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=11, dtype=torch.float32)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(8, 1, 16, 64, 64, generator=g)
+    t = torch.tensor([500, 20, 999, 0, 1, 250, 750, 998])
+    ref = R.unet_forward(p, cfg, x, t).double()
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    m = Unet3D(rngs=0, mode='bf16', **kw)
+    m.load_state_dict(p)
+    m.act_bf16 = True
+    assert _rel(m(x, t).cpu().double(), ref) < TOL_ACT16
