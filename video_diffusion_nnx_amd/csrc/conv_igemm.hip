@@ -285,25 +285,49 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
         }
         int dy = 0, dx = 0;
         for (int tap = 0; tap < ntaps; ++tap) {
+#if defined(VDX_DIAG_NOWLOAD)                             // timing diagnostics (tools/conv_diag.sh): compile-time only, results are WRONG
+            if (cc == 0 && tap == 0) wstore(buf);
+#else
             wstore(buf);
+#endif
+#if defined(VDX_DIAG_NOBAR)
+            if (tap == 0) __syncthreads();
+#else
             __syncthreads();
+#endif
             int ndy = dy, ndx = dx + 1, ncc = cc;
             if (ndx == KW) { ndx = 0; ndy = dy + 1; }
             if (ndy == KH) { ndy = 0; ncc = cc + 1; }
+#if !defined(VDX_DIAG_NOWLOAD)
             if (ncc < nchunks) wload(ndy, ndx, ncc);      // prefetch the next weight tile while this one is consumed
+#endif
             const int tapoff = (dy * IW + dx) * RS;
             const char* wt = Ws + buf * (BC * RS) + (wc * 64 + lp) * RS + q * 16;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 uint4 bf[TN], af[TM];
+#if defined(VDX_DIAG_NOFRAG)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) bf[tn] = make_uint4(lane, tapoff, ch, tn);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) af[tm] = make_uint4(lane, tapoff, ch, tm);
+#else
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(As + pixoff[tn] + tapoff + ch * CHUNK_BYTES);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) af[tm] = *reinterpret_cast<const uint4*>(wt + tm * 16 * RS + ch * CHUNK_BYTES);
+#endif
+#if defined(VDX_DIAG_NOMFMA)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) asm volatile("" :: "v"(af[tm].x), "v"(af[tm].y), "v"(af[tm].z), "v"(af[tm].w));
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) asm volatile("" :: "v"(bf[tn].x), "v"(bf[tn].y), "v"(bf[tn].z), "v"(bf[tn].w));
+#else
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
+#endif
             }
             dy = ndy; dx = ndx;
             buf ^= 1;
