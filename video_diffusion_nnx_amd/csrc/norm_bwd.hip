@@ -50,46 +50,73 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs P) {
     float4 r0[VPL], r1[VPL], g0[VPL], g1[VPL];
 #pragma unroll
     for (int v = 0; v < VPL; ++v) { r0[v] = r1[v] = g0[v] = g1[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    for (long pix = (long)blockIdx.x * ppb + pl; pix < P.pix_per_sample; pix += (long)gridDim.x * ppb) {
-        const size_t base = ((size_t)b * P.pix_per_sample + pix) * C;
-        float4 rr[VPL];
-        float mean = 0.f, rstd = 0.f;
-        if (P.r) {                                               // LayerNorm statistics of this pixel
-            float s = 0.f, ss = 0.f;
+    // U pixels per lane group and pass: every load of the pass (r, y, dact of U pixels) is issued before the first use, so a wave
+    // has 3 * U * VPL 16-byte loads in flight (the launch has < 1 wave per SIMD: nothing else hides the latency)
+    constexpr int U = VPL == 1 ? 4 : 2;
+    const long pstride = (long)gridDim.x * ppb;
+    for (long pix0 = (long)blockIdx.x * ppb + pl; pix0 < P.pix_per_sample; pix0 += pstride * U) {
+        float4 rr[U][VPL], yv4[U][VPL], da4[U][VPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long pix = pix0 + u * pstride;
+            const bool pv = pix < P.pix_per_sample;
+            const size_t base = ((size_t)b * P.pix_per_sample + (pv ? pix : 0)) * C;
 #pragma unroll
             for (int v = 0; v < VPL; ++v) {
                 const int c = (v * LPP + sub) * 4;
-                rr[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < C) {
-                    rr[v] = *reinterpret_cast<const float4*>(P.r + base + c);
-                    s += rr[v].x + rr[v].y + rr[v].z + rr[v].w;
-                    ss += rr[v].x * rr[v].x + rr[v].y * rr[v].y + rr[v].z * rr[v].z + rr[v].w * rr[v].w;
-                }
+                const size_t e = base + (c < C ? c : 0);
+                rr[u][v] = P.r ? *reinterpret_cast<const float4*>(P.r + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (P.y_bf16) {
+                    const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.y) + e * 2);
+                    yv4[u][v] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), 0.f, 0.f);      // raw, widened below
+                } else yv4[u][v] = *reinterpret_cast<const float4*>(P.y + e);
+                da4[u][v] = *reinterpret_cast<const float4*>(P.dact + e);
             }
-            for (int o = 1; o < LPP; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-            mean = s * invC;
-            rstd = rsqrtf(fmaxf(ss * invC - mean * mean, 0.f) + NORM_EPS);
         }
 #pragma unroll
-        for (int v = 0; v < VPL; ++v) {
-            const int c = (v * LPP + sub) * 4;
-            if (c < C) {
-                const float4 y = load4_f32_or_bf16(P.y, base + c, P.y_bf16);
-                const float4 da = *reinterpret_cast<const float4*>(P.dact + base + c);
-                const float yv[4] = {y.x, y.y, y.z, y.w}, dv[4] = {da.x, da.y, da.z, da.w};
-                float* p0 = &r0[v].x; float* p1 = &r1[v].x;
+        for (int u = 0; u < U; ++u) {
+            const long pix = pix0 + u * pstride;
+            const bool pv = pix < P.pix_per_sample;                 // (uniform per lane group; masked lanes contribute zeros)
+            float mean = 0.f, rstd = 0.f;
+            if (P.r) {                                               // LayerNorm statistics of this pixel
+                float s = 0.f, ss = 0.f;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float z = fmaf(yv[e], ta[c + e], td[c + e]);
-                    const float dz = dv[e] * dsilu_f(z);
-                    p0[e] += dz;
-                    p1[e] += dz * (yv[e] - mu[c + e]) * rsd[c + e];
+                for (int v = 0; v < VPL; ++v) {
+                    const int c = (v * LPP + sub) * 4;
+                    if (c < C) {
+                        s += rr[u][v].x + rr[u][v].y + rr[u][v].z + rr[u][v].w;
+                        ss += rr[u][v].x * rr[u][v].x + rr[u][v].y * rr[u][v].y + rr[u][v].z * rr[u][v].z + rr[u][v].w * rr[u][v].w;
+                    }
                 }
-                if (P.r) {
-                    const float rv[4] = {rr[v].x, rr[v].y, rr[v].z, rr[v].w};
-                    float* q0 = &g0[v].x; float* q1 = &g1[v].x;
+                for (int o = 1; o < LPP; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+                mean = s * invC;
+                rstd = rsqrtf(fmaxf(ss * invC - mean * mean, 0.f) + NORM_EPS);
+            }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { q0[e] += dv[e] * (rv[e] - mean) * rstd; q1[e] += dv[e]; }
+            for (int v = 0; v < VPL; ++v) {
+                const int c = (v * LPP + sub) * 4;
+                if (c < C && pv) {
+                    float4 y = yv4[u][v];
+                    if (P.y_bf16) {
+                        const unsigned t0 = __float_as_uint(y.x), t1 = __float_as_uint(y.y);
+                        y = make_float4(__uint_as_float(t0 << 16), __uint_as_float(t0 & 0xFFFF0000u), __uint_as_float(t1 << 16), __uint_as_float(t1 & 0xFFFF0000u));
+                    }
+                    const float4 da = da4[u][v];
+                    const float yv[4] = {y.x, y.y, y.z, y.w}, dv[4] = {da.x, da.y, da.z, da.w};
+                    float* p0 = &r0[v].x; float* p1 = &r1[v].x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z = fmaf(yv[e], ta[c + e], td[c + e]);
+                        const float dz = dv[e] * dsilu_f(z);
+                        p0[e] += dz;
+                        p1[e] += dz * (yv[e] - mu[c + e]) * rsd[c + e];
+                    }
+                    if (P.r) {
+                        const float rv[4] = {rr[u][v].x, rr[u][v].y, rr[u][v].z, rr[u][v].w};
+                        float* q0 = &g0[v].x; float* q1 = &g1[v].x;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { q0[e] += dv[e] * (rv[e] - mean) * rstd; q1[e] += dv[e]; }
+                    }
                 }
             }
         }
