@@ -1,0 +1,13 @@
+"""Just the dominant conv shape of the bench (3x3, 128 -> 128, level 1, bf16 tensors, B = CONV_B): target of pmc_passes.sh."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from video_diffusion_nnx_amd import ops
+B, Fr, mode = int(os.environ.get('CONV_B', 32)), 16, 'bf16'
+dev = torch.device('cuda:0')
+cin, cout, s = 128, 128, 32
+x = torch.randn(B, Fr, s, s, cin, device=dev).to(torch.bfloat16)
+w = torch.randn(1, 3, 3, cin, cout, device=dev) / (9 * cin) ** 0.5
+pw = ops.pack_conv_weights(w, mode); bias = torch.zeros(cout, device=dev); so = ops.gn_stats_zeros(B, 8, dev)
+for _ in range(6):
+    ops.conv_forward(x, pw, cout, mode=mode, bias=bias, k=3, out_stats=so, y_bf16=True)
+torch.cuda.synchronize()
