@@ -73,7 +73,8 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     t.dact = g; t.y = b.slot(r.s_y2); t.y_bf16 = (m->mode == MODE_BF16); t.dy = L.t1; t.stats = b.stat(r.st2); t.gamma = b.p + r.b2_gs; t.beta = b.p + r.b2_gb; t.groups = G;
     t.d_gamma = b.grads + r.b2_gs; t.d_beta = b.grads + r.b2_gb;
     t.r = rsrc; t.ln_gamma = b.p + r.n2_s; t.dr = L.t2; t.d_ln_gamma = b.grads + r.n2_s; t.d_ln_beta = b.grads + r.n2_b;
-    t.R = b.normscr; t.G = b.normscr + (size_t)b.B * r.cout * 2; t.C = r.cout; t.batch = b.B; t.pix_per_sample = b.pix(lvl);
+    // R at a fixed offset of the scratch: zeroed once per backward, the finalize pass leaves it zero again
+    t.G = b.normscr; t.R = b.normscr + (size_t)b.B * 64; t.r_clean = 1; t.C = r.cout; t.batch = b.B; t.pix_per_sample = b.pix(lvl);
     b.ok(launch_norm_bwd(t, b.st));
     // 2. conv2: y2 = conv(SiLU(GN1(y1)*(1+s)+sh))
     const float* ssrow = r.has_mlp ? b.ss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
@@ -85,7 +86,7 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     q.dact = L.t3; q.y = b.slot(r.s_y1); q.y_bf16 = (m->mode == MODE_BF16); q.dy = L.t1; q.stats = b.stat(r.st1); q.gamma = b.p + r.b1_gs; q.beta = b.p + r.b1_gb; q.groups = G;
     q.ss = ssrow; q.ss_stride = 2 * r.cout; q.d_gamma = b.grads + r.b1_gs; q.d_beta = b.grads + r.b1_gb;
     q.dss = r.has_mlp ? b.dss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
-    q.R = b.normscr; q.G = b.normscr + (size_t)b.B * r.cout * 2; q.C = r.cout; q.batch = b.B; q.pix_per_sample = b.pix(lvl);
+    q.G = b.normscr; q.R = b.normscr + (size_t)b.B * 64; q.r_clean = 1; q.C = r.cout; q.batch = b.B; q.pix_per_sample = b.pix(lvl);
     b.ok(launch_norm_bwd(q, b.st));                                                                    // t1 = dL/d(y1)
     // 4. conv1 + residual branch
     wgrad(b, x0, c0, x1, c1, L.t1, r.cout, r.b1_w, r.b1_b, lvl, 0, 3, 1);
@@ -265,6 +266,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             VDX_E(hipMemsetAsync(grads, 0, (size_t)m->param_total * 4, st));
             VDX_E(hipMemsetAsync(b.dss, 0, (size_t)m->ss_floats_per_sample * B * 4, st));
             VDX_E(hipMemsetAsync(b.dtemb, 0, (size_t)m->temb_dim * B * 4, st));
+            VDX_E(hipMemsetAsync(b.normscr, 0, (size_t)B * (2 * 1024 + 64) * 4, st));
             // head: out = conv1x1(fin(concat(x_up, r)))
             const Level& U = m->ups[nl - 1];
             VDX_E(launch_final_conv_bwd(b.slot(m->fin.s_out), d_out, params + m->fin_w, b.lv[0].ga, grads + m->fin_w, grads + m->fin_b, pix0, c.dim, m->out_dim, st));

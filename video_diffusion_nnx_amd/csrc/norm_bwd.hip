@@ -154,6 +154,7 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(NormBwdArgs P) {
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         const float R0 = P.R[((size_t)b * C + c) * 2], R1 = P.R[((size_t)b * C + c) * 2 + 1];
+        *reinterpret_cast<float2*>(P.R + ((size_t)b * C + c) * 2) = make_float2(0.f, 0.f);      // leave the scratch clean for the next call
         float sc = 1.f;
         if (P.ss) sc = P.ss[(size_t)b * P.ss_stride + c] + 1.f;
         const float ga = P.gamma[c], be = P.beta[c];
@@ -263,8 +264,10 @@ hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st) {
     // SIMD several waves, few enough that the per-workgroup table build and the 2C..4C atomics of the flush stay small
     static const int red_wgs = getenv("VDX_NORMBWD_WGS") ? atoi(getenv("VDX_NORMBWD_WGS")) : 192;
     const int gx = (int)std::max<long>(1, std::min<long>((a.pix_per_sample + ppb - 1) / ppb, std::max(1, red_wgs / std::max(1, a.batch))));
-    hipError_t e = hipMemsetAsync(a.R, 0, (size_t)a.batch * a.C * 2 * 4, st);
-    if (e != hipSuccess) return e;
+    if (!a.r_clean) {
+        hipError_t e = hipMemsetAsync(a.R, 0, (size_t)a.batch * a.C * 2 * 4, st);
+        if (e != hipSuccess) return e;
+    }
     dim3 grid(gx, a.batch);
     switch (vpl) {
         case 1: hipLaunchKernelGGL(norm_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, a); break;

@@ -159,6 +159,7 @@ struct NormBwdArgs {
     float* dss;                                                   // [B][2C] (ds | dsh) written, or null
     const float* r; const float* ln_gamma; float* dr; float* d_ln_gamma; float* d_ln_beta;   // LN branch (tail) or nulls
     float* R; float* G;                                           // scratch: [B][C][2], [B][groups][2]
+    int r_clean;                                                  // R is already zero (the finalize pass leaves it zero again): no memset
     int C, batch; long pix_per_sample;
     int lpp;
 };
