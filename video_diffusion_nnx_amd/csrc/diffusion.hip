@@ -122,9 +122,9 @@ __global__ __launch_bounds__(256) void p_sample_kernel(PSampleArgs P) {
 }
 
 __global__ void advance_kernel(int* t, int B, unsigned long long* dev_offset) {
-    const int i = threadIdx.x;
-    if (i < B && t[i] > 0) t[i] -= 1;
-    if (i == 0 && dev_offset) *dev_offset += 1;
+    for (int i = threadIdx.x; i < B; i += blockDim.x)         // one workgroup strides over the batch (any B)
+        if (t[i] > 0) t[i] -= 1;
+    if (threadIdx.x == 0 && dev_offset) *dev_offset += 1;
 }
 
 // sum over all elements of |eps_hat - eps| or (eps_hat - eps)^2 -> acc[0] (double); host divides by the count

@@ -30,7 +30,13 @@ struct Bwd {
     bool ok(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; return e == hipSuccess; }
 };
 
-size_t lvl_width(const Model* m, int l) { return (size_t)m->cfg.dim * m->cfg.dim_mults[l]; }
+// widest tensor a level's backward buffers hold: its own width, or the width of the level that feeds it (the input gradient of
+// downs[l].res0 and the output of ups[.].res0 have dims[l] channels, which exceeds dims[l+1] for non-monotone dim_mults; the
+// stem width at level 0)
+size_t lvl_width(const Model* m, int l) {
+    const size_t w = (size_t)m->cfg.dim * m->cfg.dim_mults[l];
+    return std::max(w, l == 0 ? (size_t)m->init_dim : (size_t)m->cfg.dim * m->cfg.dim_mults[l - 1]);
+}
 
 // data gradient through a conv: out[.., cin_rows] = conv(dy; transposed packing rows [row0, row0+nrows)) (+ res)
 void dgrad(Bwd& b, const float* dy, int Cdy, const void* wpt, int rows_total, int row0, int nrows, int lvl_in, int kind_fwd, int k,
@@ -194,6 +200,14 @@ void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, fl
 
 float* other(const LevelBufs& L, const float* cur) { return cur == L.ga ? L.gb : L.ga; }
 
+// time-MLP (Linear + LayerNorm) backward of the ResnetBlocks [first, first + count) of Model::ss_layers.  Called at the end of the
+// stage that owns the blocks, so every parameter gradient of a stage is final when the stage returns (the data-parallel reducer
+// all-reduces a bucket as soon as its last stage has been enqueued); d(temb) accumulates across stages and is consumed by the stem.
+void ss_bwd(Bwd& b, int first, int count) {
+    if (first < 0 || count <= 0) return;
+    b.ok(launch_resblock_ss_bwd(b.p, b.grads, b.temb, b.m->d_ss_layers + first, count, b.ss_lin, b.dss, b.dtemb, b.m->temb_dim, b.B, b.st));
+}
+
 }  // namespace
 
 static size_t al(size_t floats) { return (floats + 63) / 64 * 64; }
@@ -203,7 +217,7 @@ size_t model_bwd_workspace_bytes(const Model* m, int B) {
     size_t fl = 0;
     for (int l = 0; l < nl; ++l) {
         const long s = m->cfg.image_size >> l;
-        fl += 6 * al((size_t)B * m->cfg.num_frames * s * s * std::max<size_t>(lvl_width(m, l), m->init_dim));
+        fl += 6 * al((size_t)B * m->cfg.num_frames * s * s * lvl_width(m, l));
     }
     const size_t pix0 = (size_t)B * m->cfg.num_frames * m->cfg.image_size * m->cfg.image_size;
     fl += al(pix0 * m->init_dim);                                  // gr
@@ -245,7 +259,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
         b.lv.resize(nl);
         for (int l = 0; l < nl; ++l) {
             const long s = c.image_size >> l;
-            const size_t n = al((size_t)B * c.num_frames * s * s * std::max<size_t>(lvl_width(m, l), m->init_dim));
+            const size_t n = al((size_t)B * c.num_frames * s * s * lvl_width(m, l));
             b.lv[l].ga = w; w += n; b.lv[l].gb = w; w += n; b.lv[l].t1 = w; w += n; b.lv[l].t2 = w; w += n; b.lv[l].t3 = w; w += n; b.lv[l].gskip = w; w += n;
         }
         const size_t pix0 = (size_t)B * c.num_frames * c.image_size * c.image_size;
@@ -293,6 +307,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             const int cx = (i == 0) ? m->mid2.cout : m->ups[i - 1].cout;
             o = other(LB, g);
             res_bwd(b, L.res0, g, xin, cx, b.slot(D.s_attn), D.cout, lvl, o, LB.gskip); g = o;
+            ss_bwd(b, L.res0.ss_index, 2);
         } else if (stage == nl + 1) {
             const int lvl = nl - 1;
             LevelBufs& LB = b.lv[lvl];
@@ -303,6 +318,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             const Level& D = m->downs[nl - 1];
             o = other(LB, g);
             res_bwd(b, m->mid1, g, b.slot(D.s_attn), D.cout, nullptr, 0, lvl, o, nullptr); g = o;
+            ss_bwd(b, m->mid1.ss_index, 2);
         } else if (stage >= 1) {
             const int i = stage - 1;
             const Level& L = m->downs[i];
@@ -323,6 +339,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             const float* xin = (i == 0) ? b.slot(m->s_init_attn) : b.slot(m->downs[i - 1].s_rs);
             o = other(LB, g);
             res_bwd(b, L.res0, g, xin, L.cin, nullptr, 0, i, o, nullptr); g = o;
+            ss_bwd(b, L.res0.ss_index, 2);
         } else {
             // stem: r gradient joins, init temporal attention, init conv, time-embedding MLPs
             LevelBufs& LB = b.lv[0];
@@ -331,7 +348,6 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             attn_bwd(b, m->init_attn, g, b.slot(m->s_init), 0, true, o); g = o;
             VDX_E(launch_init_conv_wgrad(x, g, grads + m->init_w, grads + m->init_b, B, c.channels, c.num_frames, c.image_size, c.image_size,
                                          m->init_dim, c.init_kernel_size, st));
-            VDX_E(launch_resblock_ss_bwd(params, grads, b.temb, m->d_ss_layers, (int)m->ss_layers.size(), b.ss_lin, b.dss, b.dtemb, m->temb_dim, B, st));
             TimeMlpArgs t;
             memset(&t, 0, sizeof(t));
             t.time = time; t.w1 = params + m->t_w1; t.b1 = params + m->t_b1; t.w2 = params + m->t_w2; t.b2 = params + m->t_b2;

@@ -9,7 +9,8 @@ struct vdx_handle {
     vdx::Model model;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    struct GraphKey { const void* p[8]; unsigned long long seed; int i[4]; size_t ws; } graph_key;
+    // every argument the captured step bakes in (full pointers: two workspaces / streams never alias one key)
+    struct GraphKey { const void* p[10]; unsigned long long seed; int i[4]; size_t ws; } graph_key;
     vdx::BwdState bwd;
 };
 
@@ -329,7 +330,7 @@ int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, fl
     memset(&key, 0, sizeof(key));
     key.p[0] = params; key.p[1] = packed; key.p[2] = img; key.p[3] = eps_buf; key.p[4] = t_dev; key.p[5] = step_dev;
     key.p[6] = tables; key.p[7] = cond; key.seed = seed; key.i[0] = timesteps; key.i[1] = clip_denoised | (h->model.act16 << 8); key.i[2] = batch;
-    key.i[3] = (int)(uintptr_t)workspace; key.ws = workspace_bytes ^ (size_t)(uintptr_t)stream;
+    key.p[8] = workspace; key.p[9] = stream; key.ws = workspace_bytes;
     int done = 0;
     if (!h->graph_exec || memcmp(&key, &h->graph_key, sizeof(key)) != 0) {
         if (nsteps == 0) return VDX_OK;

@@ -33,8 +33,11 @@ def stage_of_param(name: str, n_levels: int) -> int:
     raise KeyError(name)
 
 
-def run_train_step(tr, batch: torch.Tensor, step: int) -> torch.Tensor:
-    """loss, grads = value_and_grad(p_losses); Adam; EMA  (trainer.py:337-382) for this rank's shard of the batch."""
+def run_train_step(tr, batch: torch.Tensor, step: int, t: torch.Tensor = None, noise: torch.Tensor = None) -> torch.Tensor:
+    """loss, grads = value_and_grad(p_losses); Adam; EMA  (trainer.py:337-382) for this rank's shard of the batch.
+
+    `t` [B] / `noise` [B,C,F,H,W] override this rank's own draws (the reference threads `noise` through p_losses the same way,
+    gaussian_diffusion.py:423-445); the data-parallel tests use them to give N ranks the shards of ONE global draw."""
     from .trainer import GradBucketReducer
     gd, unet = tr.model, tr.unet
     dev = tr.device
@@ -46,9 +49,11 @@ def run_train_step(tr, batch: torch.Tensor, step: int) -> torch.Tensor:
     step_key = split_key(split_key(tr.rng_seed, tr.rank + 1)[-1], step + 1)[-1]
     _, t_key, loss_key = split_key(step_key, 3)
     _, noise_key, _ = split_key(loss_key, 3)
-    g = torch.Generator().manual_seed(t_key & 0x7FFFFFFFFFFFFFFF)
-    t = torch.randint(0, gd.num_timesteps, (B,), generator=g, dtype=torch.int32).to(dev)
-    noise = gd.randn(x.shape, noise_key, 0)
+    if t is None:
+        g = torch.Generator().manual_seed(t_key & 0x7FFFFFFFFFFFFFFF)
+        t = torch.randint(0, gd.num_timesteps, (B,), generator=g, dtype=torch.int32)
+    t = torch.as_tensor(t).to(dev, torch.int32)
+    noise = gd.randn(x.shape, noise_key, 0) if noise is None else torch.as_tensor(noise).to(dev, torch.float32).contiguous()
     tr.last_t, tr.last_noise_key = t, noise_key
     x_noisy = gd.q_sample(x, t, noise=noise, _pre=(2.0, -1.0))                    # normalize_img folded in (:499)
     eps_hat = unet(x_noisy, t)

@@ -91,6 +91,10 @@ class GradBucketReducer:
 
 
 class Trainer:
+    # gradient all-reduce bucket size (floats): >= 16 MB per RCCL call keeps every xGMI ring step bandwidth-bound; the
+    # constructor signature stays the reference's, so this is a class attribute
+    min_bucket_floats = 4 << 20
+
     def __init__(self, diffusion_model, folder: str, *, rng_seed: int = 0, dataset_path: str, num_frames: int = 16,
                  train_batch_size: int = 4, train_lr: float = 1e-4, train_num_steps: int = 100000,
                  gradient_accumulate_every: int = 2, step_start_ema: int = 2000, update_ema_every: int = 10,
@@ -116,6 +120,10 @@ class Trainer:
         self.world = dist.get_world_size() if self.dist_on else 1
         self.rank = dist.get_rank() if self.dist_on else 0
         assert train_batch_size % self.world == 0, 'batch_size must be divisible by number of devices'     # trainer.py:163
+        if self.dist_on and self.device.type == 'cuda':
+            # parameters, gradients and workspaces must live on the GPU this rank's process group and HIP stream are bound to
+            assert self.device.index == torch.cuda.current_device(), \
+                f'Unet3D lives on {self.device} but this rank runs on cuda:{torch.cuda.current_device()}: build the model after torch.cuda.set_device(LOCAL_RANK)'
         self.batch_size = train_batch_size
         self.per_device_bs = train_batch_size // self.world
         # ---- optimizer state: Adam m, v + EMA copy, flat like the parameters ----
@@ -127,7 +135,8 @@ class Trainer:
         self.opt_count = 0                                       # optax count: restarts at 0 on resume
         from .train_step import stage_of_param
         nlev = len(self.unet.dim_mults)
-        self.buckets = make_buckets(self.unet.param_table, n, lambda nm: stage_of_param(nm, nlev), stage_of_param('__count__', nlev))
+        self.buckets = make_buckets(self.unet.param_table, n, lambda nm: stage_of_param(nm, nlev), stage_of_param('__count__', nlev),
+                                    min_bucket_floats=self.min_bucket_floats)
         # ---- dataset ----
         self.image_size = diffusion_model.image_size
         if str(dataset_path).startswith('synthetic'):
@@ -182,10 +191,11 @@ class Trainer:
         except Exception as e:                                   # reference: log and continue (trainer.py:595-602)
             logging.error(f'Error saving checkpoint at step {step}: {e}')
 
-    def train_step(self, batch: torch.Tensor, step: int) -> torch.Tensor:
-        """One `_pjit_train_step` on this rank's shard of the batch.  Returns the (device) scalar loss of the shard."""
+    def train_step(self, batch: torch.Tensor, step: int, t=None, noise=None) -> torch.Tensor:
+        """One `_pjit_train_step` on this rank's shard of the batch.  Returns the (device) scalar loss of the shard.
+        t / noise: optional explicit timesteps / noise of the shard (default: this rank's own Philox draws)."""
         from .train_step import run_train_step
-        return run_train_step(self, batch, step)
+        return run_train_step(self, batch, step, t=t, noise=noise)
 
     def train(self, prob_focus_present: float = 0.0, focus_present_mask=None, log_fn=noop):
         assert callable(log_fn)

@@ -136,7 +136,13 @@ class Unet3D:
         # bf16 mode only: store every inter-kernel activation as bf16 (inference).  GaussianDiffusion turns it on for its
         # sampling loops; forwards that feed backward() need it off (the backward reads the fp32 slots).
         self.act_bf16 = False
-        self.device = torch.device(device) if device is not None else torch.device('cuda:0' if torch.cuda.is_available() else 'cpu')
+        # default: the process's CURRENT device (a rank launched by torch.distributed.run has called set_device(LOCAL_RANK))
+        if device is not None:
+            self.device = torch.device(device)
+            if self.device.type == 'cuda' and self.device.index is None:
+                self.device = torch.device('cuda', torch.cuda.current_device())
+        else:
+            self.device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
         self._handles: Dict[Tuple[int, int], _Handle] = {}
         self._ws: Dict[Tuple[int, int, int], torch.Tensor] = {}
         self._packed: Optional[torch.Tensor] = None
