@@ -1,6 +1,10 @@
 """bench.py -- denoised frames/sec of the DDPM sampling hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N ...`: WORLD_SIZE is set) or, when WORLD_SIZE is unset, this process spawns them itself through
+torch.distributed.run and relays rank 0's JSON line -- the parent never touches the GPU.
 
 A "step" is ONE reverse-diffusion step (Unet3D forward + p_sample) over the per-GPU batch, replayed from a hipGraph.
 Workload = BASELINE.json configs[1] ("config_v2_2 Unet3D dim=64, 16-frame 64x64, 1000-step p_sample_loop bf16"),
@@ -13,14 +17,13 @@ import os
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 T_STEPS = 1000
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense peaks, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_FILES = ('r02_traffic.json', 'r01_traffic.json')        # newest first
 
 
 def conv_layers(dim, mults, frames, size, batch):
@@ -74,6 +77,7 @@ def conv_bytes(layer, frames, batch, mode, act='f32'):
 def time_conv_kernels(unet, frames, size, batch, mode, act='f32', reps=5):
     """Roofline leg: replays every conv_igemm launch shape of one forward standalone (tensors in the storage type the timed
     region used), HIP events on the launch stream."""
+    import torch
     from video_diffusion_nnx_amd import ops
     dev = unet.device
     per_symbol = {}
@@ -130,6 +134,7 @@ def time_conv_kernels(unet, frames, size, batch, mode, act='f32', reps=5):
 
 def cpu_baseline(dim, frames, size, budget_s=20.0):
     """CPU restatement (PyTorch-CPU, NOT JAX) of the same UNet forward at B=1, timed on this node's host cores."""
+    import torch
     from oracle import unet3d_ref as R
     cfg = R.UnetConfig(dim=dim, channels=1)
     p = R.random_params(cfg, seed=0)
@@ -154,7 +159,7 @@ def log(msg):
 _T0 = time.time()
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
@@ -168,18 +173,106 @@ def main():
                     help='storage of the inter-kernel activations (auto: bf16 in bf16 mode, as GaussianDiffusion.sample does)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    args = ap.parse_args()
+    ap.add_argument('--no-train', action='store_true', help='skip the training leg (p_losses fwd+bwd, bucketed all-reduce, Adam/EMA)')
+    ap.add_argument('--train-batch', type=int, default=4, help='training samples per GPU (BASELINE.json configs[2]: 4)')
+    ap.add_argument('--train-steps', type=int, default=10)
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args):
+    """--gpus N > 1 without a launcher: start N ranks through torch.distributed.run (one per GPU, RCCL over xGMI) as a child
+    process and pass its output through.  Nothing here imports torch or initialises HIP: the parent only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                                  # a free rendezvous port on the loopback interface
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f'spawning {args.gpus} ranks: {" ".join(cmd)}')
+    return subprocess.call(cmd, env=env)
+
+
+def train_leg(args, dev, world, rank):
+    """Secondary metric: training samples/s of BASELINE.json configs[2] -- p_losses forward + staged backward with the
+    bucketed gradient all-reduce (RCCL) issued per finished stage + Adam/EMA, batch 4 per GPU at the north-star shape.
+    allreduce_exposed_ms = step time with the all-reduce minus step time without it (max over ranks both)."""
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from video_diffusion_nnx_amd import trainer as T
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    B, Fr, S = args.train_batch, args.frames, args.size
+    unet = Unet3D(dim=args.dim, rngs=0, channels=1, mode=args.mode, device=dev)
+    gd = GaussianDiffusion(unet, image_size=S, num_frames=Fr, channels=1, timesteps=T_STEPS, loss_type='l2')
+    tmp = tempfile.mkdtemp(prefix=f'vdx_bench_r{rank}_')
+    tr = T.Trainer(gd, tmp, dataset_path='synthetic:8', train_batch_size=B * world, train_num_steps=10 ** 9, results_folder=tmp)
+    g = torch.Generator().manual_seed(1000 + rank)                # S2 of SURVEY 8d: x0 ~ U[0,1), seed 1000 + rank
+    x = torch.rand(B, 1, Fr, S, S, generator=g).to(dev)
+
+    def timed(n, first):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n):
+            tr.train_step(x, first + i)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = tt.item()
+        return dt / n * 1e3
+    timed(3, 0)                                                   # warm-up (first-call kernel attributes, allocator, RCCL channels)
+    ms = timed(args.train_steps, 3)
+    exposed = 0.0
+    if world > 1:
+        reducer_cls = T.GradBucketReducer
+        class _NoComm(reducer_cls):                               # same step, gradient all-reduce switched off (timing only)
+            def __init__(self, *a, **k):
+                super().__init__(*a, **k)
+                self.enabled = False
+        T.GradBucketReducer = _NoComm
+        try:
+            timed(2, 100)
+            ms_nocomm = timed(args.train_steps, 102)
+        finally:
+            T.GradBucketReducer = reducer_cls
+        exposed = max(0.0, ms - ms_nocomm)
+    n_buckets = len(tr.buckets)
+    return {'samples_per_s': world * B / (ms * 1e-3), 'ms_per_step': ms, 'batch_per_gpu': B, 'global_batch': B * world,
+            'allreduce_exposed_ms': exposed, 'grad_bytes': int(unet.flat_params.numel()) * 4, 'buckets': n_buckets,
+            'what': 'q_sample + Unet3D fwd (fp32 activation storage) + l2 loss + staged backward + bucketed sum all-reduce + Adam + EMA'}
+
+
+def main():
+    args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (the HIP path has no CPU fallback)'
+    if args.gpus != world:
+        log(f'warning: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
+    backend = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
+        backend = f'{dist.get_backend()} (RCCL), world_size {dist.get_world_size()}'
+        log(f'rank {rank}/{world} on cuda:{local}: process group up: {backend}')
 
     from video_diffusion_nnx_amd import _lib as L
     from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion, vdx_p_sample_loop
@@ -233,11 +326,19 @@ def main():
         'config': {'workload': f'config_v2_2 (north-star shape): Unet3D dim={args.dim} C=1, {Fr}f x {S}x{S}, DDPM T={T_STEPS} p_sample_loop '
                                f'(UNet forward + p_sample per step, hipGraph replay); value = n_gpus*B*F/(T*s_per_step)',
                    'batch_per_gpu': B, 'timesteps': T_STEPS, 'parallelism': f'dp{world} (independent samples, no collective)',
-                   'mfma_operands': args.mode, 'storage': f'weights fp32 master, activations {act}, fp32 accumulate'},
+                   'mfma_operands': args.mode, 'storage': f'weights fp32 master, activations {act}, fp32 accumulate',
+                   'process_group': backend or 'none (single process)'},
     }
     log(f'timed region done: {ms_per_step:.3f} ms/step')
+    del img, eps, ws
+    unet._ws.clear()
+    torch.cuda.empty_cache()
+    if not args.no_train:
+        log('training leg (p_losses fwd+bwd + bucketed all-reduce + Adam/EMA) ...')
+        line['train'] = train_leg(args, dev, world, rank)         # every rank takes part (collectives inside)
+        log(f"training leg done: {line['train']['ms_per_step']:.2f} ms/step, {line['train']['samples_per_s']:.1f} samples/s")
     if rank == 0 and not args.no_roofline:
-        log('roofline leg: replaying conv_igemm launch shapes ...')
+        log('roofline leg: replaying conv launch shapes ...')
         with torch.cuda.stream(stream):
             per = time_conv_kernels(unet, Fr, S, B, args.mode, act)
         sym, d = max(per.items(), key=lambda kv: kv[1]['ms'])
@@ -246,17 +347,23 @@ def main():
         mfma_peak = MFMA_PEAK_TFLOPS[args.mode]
         # which roofline binds this kernel: arithmetic intensity against the machine balance (peak FLOP/s / peak B/s)
         hbm_bound = (d['flops'] / d['bytes']) < (mfma_peak * 1e12) / (HBM_PEAK_GBS * 1e9)
-        traffic = None                                   # HBM bytes per launch from committed rocprofv3 PMC passes of THIS workload
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if os.path.exists(tpath):
+        traffic, traffic_source = None, None             # HBM bytes per launch from committed rocprofv3 PMC passes of THIS workload
+        for tname in TRAFFIC_FILES:
+            tpath = os.path.join(ROOT, 'profiles', tname)
+            if not os.path.exists(tpath):
+                continue
             tj = json.load(open(tpath))
             if (tj.get('batch') == B and tj.get('mode') == args.mode and tj.get('dim') == args.dim and tj.get('act', 'f32') == act
                     and sym in tj.get('kernels', {})):
                 traffic = tj['kernels'][sym]['hbm_bytes_per_launch']
+                traffic_source = (f'profiles/{tname}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH doubled per '
+                                  'MI355X_MICROARCH.md), committed -- NOT collected in this run')
+                break
         line['roofline'] = {'bound': 'hbm' if hbm_bound else 'mfma',
                             'achieved': gbs if hbm_bound else tflops, 'peak': HBM_PEAK_GBS if hbm_bound else mfma_peak,
                             'unit': 'GB/s' if hbm_bound else 'TFLOP/s', 'frac': (gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / mfma_peak),
-                            'traffic': traffic, 'kernel': sym, 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
+                            'traffic': traffic, 'traffic_source': traffic_source,
+                            'kernel': sym, 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
                             'avg_algorithmic_mb_per_launch': d['bytes'] / d['launches'] / 1e6,
                             'avg_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                             'arithmetic_intensity_flop_per_byte': d['flops'] / d['bytes'],
@@ -270,6 +377,7 @@ def main():
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

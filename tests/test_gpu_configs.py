@@ -68,8 +68,9 @@ def n_shape_reference():
 
 
 # f32: exact-f32 MFMA products, fp32 storage.  bf16: bf16 MFMA operands everywhere (forward, data and weight gradients,
-# attention cores), fp32 accumulate; measured 2.6e-2 over all 35.7 M parameters at this shape (r02), stated 4e-2.
-@pytest.mark.parametrize('mode,tol', [('f32', 2e-4), ('bf16', 4e-2)])
+# attention cores), fp32 accumulate; measured 1.35e-2 over all 35.7 M parameters at this shape (r02; worst tensors: the q/k
+# projections of the C = 256 / 512 temporal attention at 6-7e-2), stated 2.5e-2.
+@pytest.mark.parametrize('mode,tol', [('f32', 2e-4), ('bf16', 2.5e-2)])
 def test_unet_backward_north_star_shape(n_shape_reference, mode, tol):
     from video_diffusion_nnx_amd.unet3d import Unet3D
     cfg, p64, x, t, d_out, ref_out, ref_grads = n_shape_reference
@@ -155,7 +156,7 @@ def _p_losses_step(tmp_path, ukw, frames, size, T, B, mode, tol_loss, tol_grad):
     assert tr.opt_count == 1 and torch.isfinite(unet.flat_params).all()
 
 
-@pytest.mark.parametrize('mode,tl,tg', [('f32', 2e-5, 3e-4), ('bf16', 2e-2, 6e-2)])
+@pytest.mark.parametrize('mode,tl,tg', [('f32', 2e-5, 3e-4), ('bf16', 2e-2, 2e-2)])
 def test_config_v1_0_as_written_p_losses_step(tmp_path, mode, tl, tg):
     """configs/config_v1_0.yaml: dim 32, channels 1, image 64, frames 2, T 200, l2, batch 16 (reference configs/config_v1_0.yaml:3-24)."""
     import yaml, pathlib
@@ -166,7 +167,7 @@ def test_config_v1_0_as_written_p_losses_step(tmp_path, mode, tl, tg):
                    d['timesteps'], tc['train_batch_size'], mode, tl, tg)
 
 
-@pytest.mark.parametrize('mode,tl,tg', [('f32', 2e-5, 3e-4), ('bf16', 2e-2, 6e-2)])
+@pytest.mark.parametrize('mode,tl,tg', [('f32', 2e-5, 3e-4), ('bf16', 2e-2, 2e-2)])
 def test_config_v1_0_baseline_words_p_losses_step(tmp_path, mode, tl, tg):
     """BASELINE.json configs[0]: 'tiny Unet3D, 8-frame 32x32 batch=1, one p_losses step'."""
     _p_losses_step(tmp_path, dict(dim=32, channels=1), 8, 32, 200, 1, mode, tl, tg)

@@ -66,3 +66,31 @@ def test_configs_parse_with_reference_schema():
         assert {'image_size', 'num_frames', 'timesteps', 'loss_type', 'channels'} <= set(c['diffusion'])
     c = yaml.safe_load(open('configs/config_v2_2.yaml'))
     assert (c['unet']['dim'], c['diffusion']['num_frames'], c['trainer']['train_batch_size']) == (32, 10, 4)
+
+
+def test_bench_parent_spawns_ranks_without_touching_torch(monkeypatch):
+    """`python bench.py --gpus N` with no launcher: the parent must start N ranks through torch.distributed.run on 127.0.0.1
+    and must not import torch (importing it is harmless, initialising HIP in the parent is not: the driver's contract)."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, subprocess, bench\n"
+        "calls = []\n"
+        "subprocess.call = lambda cmd, env=None: (calls.append((cmd, env)), 0)[1]\n"
+        "sys.argv = ['bench.py', '--gpus', '4', '--steps', '7', '--warmup', '2']\n"
+        "try:\n"
+        "    bench.main()\n"
+        "except SystemExit as e:\n"
+        "    assert e.code == 0\n"
+        "assert 'torch' not in sys.modules, 'the spawning parent imported torch'\n"
+        "cmd, env = calls[0]\n"
+        "assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1'] and '--nproc-per-node=4' in cmd\n"
+        "assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'\n"
+        "assert cmd[-6:] == ['--gpus', '4', '--steps', '7', '--warmup', '2']\n"
+        "assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'\n"
+        "print('ok')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, '-c', code], cwd=str(ROOT), env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr
