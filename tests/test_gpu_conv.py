@@ -171,3 +171,62 @@ def test_persistent_c128_to_64_conv(concat):
     yg = ref.reshape(B, -1, 8, 8)
     np.testing.assert_allclose(s[..., 0], yg.sum(dim=(1, 3)), rtol=2e-3, atol=5.0)
     np.testing.assert_allclose(s[..., 1], (yg * yg).sum(dim=(1, 3)), rtol=2e-3)
+
+
+WS_CASES = [
+    # B, F, S, C0, C1, Cout            (3x3, stride 1, bf16 tensors, Cout % 128 == 0, >= 128 work items)
+    (2, 16, 32, 128, 0, 128),          # level-1 shape: 16 x 16 tiles of a 32 x 32 frame, one output-channel tile
+    (5, 16, 32, 64, 0, 128),           # 320 tiles over 256 ranges: ragged ranges, one K chunk
+    (4, 16, 16, 128, 128, 256),        # level-2 shape with a two-pointer concat input, two output-channel tiles per range
+    (8, 16, 8, 512, 0, 512),           # level-3 / mid shape: four whole 8 x 8 frames per tile, four output-channel tiles, ring of 3
+    (8, 8, 8, 256, 0, 128),            # F = 8: two tiles per sample
+]
+
+
+@pytest.mark.parametrize('case', WS_CASES)
+@pytest.mark.parametrize('y_bf16', [True, False])
+def test_weight_streaming_conv(case, y_bf16):
+    """conv3x3_ws_kernel (conv_ws.hip): persistent weight-streaming 3x3 conv of the wide levels.  Plain form (bias + statistics
+    epilogue, samples of different scale so the per-sample statistics flush is visible), then the fused-prologue form
+    (GroupNorm-apply * (scale + 1) + shift -> SiLU, per-sample coefficients) consuming its output."""
+    from video_diffusion_nnx_amd import ops
+    dev = torch.device('cuda:0')
+    B, Fr, S, C0, C1, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Fr, S, S, C0 + C1, generator=g)
+    x *= (1.0 + 0.25 * torch.arange(B).float()).view(B, 1, 1, 1, 1)
+    kern = torch.randn(1, 3, 3, C0 + C1, Cout, generator=g) / (9 * (C0 + C1)) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    pw = ops.pack_conv_weights(kern.to(dev), 'bf16')
+    stats1 = ops.gn_stats_zeros(B, 8, dev)
+    xd = x.to(dev).to(torch.bfloat16)
+    if C1:
+        y1 = ops.conv_forward(xd[..., :C0].contiguous(), pw, Cout, mode='bf16', bias=bias.to(dev), x1=xd[..., C0:].contiguous(),
+                              out_stats=stats1, y_bf16=y_bf16)
+    else:
+        y1 = ops.conv_forward(xd, pw, Cout, mode='bf16', bias=bias.to(dev), out_stats=stats1, y_bf16=y_bf16)
+    torch.cuda.synchronize()
+    ref1 = R.conv_1kk(_bf16r(x).double(), _bf16r(kern).double(), bias.double())
+    y1f = y1.float().cpu().double()
+    r1 = _rel(y1f, ref1)
+    assert r1 < (4e-3 if y_bf16 else 2e-6), r1               # exact bf16 products, fp32 accumulate (+ one output rounding)
+    s = ops.gn_stats_reduce(stats1, B, 8).cpu()
+    yg = ref1.reshape(B, -1, 8, Cout // 8)
+    np.testing.assert_allclose(s[..., 0], yg.sum(dim=(1, 3)), rtol=2e-3, atol=5.0)     # statistics are taken before the output rounding
+    np.testing.assert_allclose(s[..., 1], (yg * yg).sum(dim=(1, 3)), rtol=2e-3)
+    if not y_bf16:
+        return                                               # the prologue form needs bf16 input tensors
+    gamma, beta = 1 + 0.1 * torch.randn(Cout, generator=g), 0.1 * torch.randn(Cout, generator=g)
+    ss = torch.randn(B, 2 * Cout, generator=g) * 0.3
+    kern2 = torch.randn(1, 3, 3, Cout, 128, generator=g) / (9 * Cout) ** 0.5
+    pw2 = ops.pack_conv_weights(kern2.to(dev), 'bf16')
+    for use_ss in (True, False):
+        stats2 = ops.gn_stats_zeros(B, 8, dev)
+        y2 = ops.conv_forward(y1, pw2, 128, mode='bf16', in_stats=stats1, gamma=gamma.to(dev), beta=beta.to(dev),
+                              scale_shift=ss.to(dev) if use_ss else None, out_stats=stats2, y_bf16=True)
+        h = R.group_norm(y1f, gamma.double(), beta.double(), 8)
+        if use_ss:
+            h = h * (ss[:, None, None, None, :Cout].double() + 1) + ss[:, None, None, None, Cout:].double()
+        ref2 = R.conv_1kk(_bf16r(R.silu(h).float()).double(), _bf16r(kern2).double(), None)
+        r2 = _rel(y2.float().cpu().double(), ref2)
+        assert r2 < 5e-3, (use_ss, r2)

@@ -972,6 +972,7 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     const size_t b0 = npix * a.C0 * (a.x0_bf16 ? 2 : 4), b1 = npix * a.C1 * (a.x1_bf16 ? 2 : 4), bw = (size_t)(a.kind ? 16 : a.kh * a.kw) * a.wrows * a.CinPad * ES;
     if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
     a.x0_bytes = (unsigned)b0; a.x1_bytes = (unsigned)b1; a.w_bytes = (unsigned)bw;
+    if (conv3x3_ws_eligible(mode, a)) return launch_conv3x3_ws(a, st);       // wide levels: persistent weight-streaming kernel
     {   // persistent specialisation for the level-0 shape (see conv64p_kernel); VDX_CONV64P=0 disables it
         static const int use64p = getenv("VDX_CONV64P") ? atoi(getenv("VDX_CONV64P")) : 1;
         const long tiles = (long)a.NF * (a.H / 16) * (a.W / 16);
