@@ -10,9 +10,14 @@
 //   * WEIGHT STREAM: the [tap][128 couts][64 cin] slabs (16 KB) of the packed weights flow through an NS-deep LDS ring filled by
 //     LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write pass), NS - 1 slabs ahead of the MFMAs, across tile boundaries; ONE raw
 //     s_barrier per slab, guarded by a COUNTED s_waitcnt vmcnt(N) so that the younger slabs stay in flight across it.
-//   * HALO DOUBLE BUFFER: the (frames x (PH+2) x (PW+2)) x 64-channel input tile of the NEXT K chunk / pixel tile is fetched by
-//     LDS-DMA while the 9 taps of the current one run; out-of-image pixels read a zero page, so the 3x3 window needs no bounds
-//     logic.  With a prologue the issuing thread rewrites its own pieces in place (LDS -> registers -> LDS) between the taps.
+//   * INPUT DOUBLE BUFFER: the 64-channel input tile of the NEXT K chunk / pixel tile is fetched by LDS-DMA while the 9 taps of the
+//     current one run.  Two geometries: 32 x 32 and larger frames are cut in 16 x 16 tiles with an 18 x 18 halo (out-of-image pieces
+//     read a zero page, so the window needs no bounds logic); 8 x 8 and 16 x 16 frames are taken WHOLE (4 / 1 frames = 256 pixels =
+//     256 consecutive rows of the tensor) plus ONE zero row that every out-of-frame tap of every lane points at -- no border rows
+//     to fetch, to transform or to store.  With a prologue the issuing thread rewrites its own pieces in place (LDS -> registers
+//     -> LDS), one piece per tap, between the MFMAs.
+//   * FRAGMENTS ONE STEP AHEAD: a tap's sync guarantees the NEXT tap's slab, so the fragments of the next K step (the next tap's
+//     first one included) are loaded while the current 16 MFMAs run; the barrier is followed by MFMAs, not by LDS latency.
 //   * WAVE TILE 64 couts x 64 pixels (4 x 4 MFMA tiles of 16x16x32): 8 fragment reads per 16 MFMAs instead of 6 per 8.
 //   * XCD-aware decode: the workgroups that share a pixel range (one per 128-channel output tile) are 8 ids apart -> same XCD,
 //     same L2, so an input tile leaves HBM once.
@@ -55,23 +60,35 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
 
 }  // namespace
 
-// PW = tile width in pixels: 16 -> 16 x 16 pixels of one frame, 8 -> four whole 8 x 8 frames.  NS = ring depth.
-template <int PW, int NS, bool PRO>
+// GEO: 0 = 16 x 16 tiles of larger frames with an 18 x 18 halo; 8 / 16 = whole frames of that size (see the header).
+constexpr int WS_NS = 4;                      // ring depth: slab t (MFMAs), t + 1 (landed, fragments being prefetched), t + 2 (in flight), + the one being refilled
+
+template <int GEO> struct WsGeo {
+    static constexpr bool WF = GEO != 0;
+    static constexpr int S = WF ? GEO : 16;
+    static constexpr int NP = WF ? 256 / (S * S) : 1;                 // frames per tile
+    static constexpr int IW = 18;                                      // halo geometry (GEO 0 only)
+    static constexpr int HPX = WF ? 257 : 18 * 18;                     // rows of one input buffer
+    static constexpr int NPIECE = HPX * 8;
+    static constexpr int NU = (NPIECE + 511) / 512;
+    static constexpr int NUMIN = NPIECE / 512;                         // input LDS-DMA instructions EVERY wave issues per buffer
+    static constexpr int HBUF = HPX * 128;
+};
+
+template <int GEO, bool PRO>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, const int tiles_per_range, const int total_tiles, const int nct) {
     using M = Mma<MODE_BF16>;
-    constexpr int PH = PW == 16 ? 16 : 8;
-    constexpr int NP = 256 / (PW * PH);
-    constexpr int IW = PW + 2, IH = PH + 2, HPX = NP * IH * IW;
-    constexpr int NPIECE = HPX * 8;                       // 16-byte pieces of one halo buffer
-    constexpr int NU = (NPIECE + 511) / 512;
-    constexpr int NUMIN = NPIECE / 512;                   // halo LDS-DMA instructions EVERY wave issues per buffer
-    constexpr int HBUF = HPX * 128;
-    constexpr int WIN = 2 * (NS - 2);                     // weight LDS-DMA instructions younger than the slab a sync waits for
+    using G = WsGeo<GEO>;
+    constexpr bool WF = G::WF;
+    constexpr int S = G::S, NP = G::NP, IW = G::IW, HPX = G::HPX, NPIECE = G::NPIECE, NU = G::NU, NUMIN = G::NUMIN, HBUF = G::HBUF;
+    constexpr int NS = WS_NS;
+    constexpr int WIN = 2;                                // weight LDS-DMA instructions younger than the slab a sync waits for
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                    // [NS][128 rows][128 B]
     char* halo = ring + NS * WS_SLAB;                     // [2][HPX rows][128 B]
-    float* coefA = reinterpret_cast<float*>(halo + 2 * HBUF);   // PRO: [Cin] x_hat = x * a + d
+    float* biasl = reinterpret_cast<float*>(halo + 2 * HBUF);   // [128] bias of this output-channel tile
+    float* coefA = biasl + 128;                           // PRO: [Cin] x_hat = x * a + d
     float* coefD = coefA + P.CinPad;
     float* gmean = coefD + P.CinPad;                      // [32][mean, rstd]
 
@@ -86,9 +103,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
     const int range = (slot / nct) * 8 + xcd;
     const int t0 = range * tiles_per_range, t1 = min(t0 + tiles_per_range, total_tiles);
     if (t0 >= t1) return;
-    const int tiles_x = P.W / PW, tiles_pf = tiles_x * (P.H / PH);
+    const int tiles_x = WF ? 1 : P.W / 16, tiles_pf = WF ? 1 : tiles_x * (P.H / 16);     // GEO 0: tiles per frame
     const int nchunks = P.CinPad >> 6;
     const int Cin = P.C0 + P.C1;
+    const int fpt = NP;                                   // frames per tile
+    auto sample_of = [&](int t) { return WF ? (t * fpt) / P.F : (t / tiles_pf) / P.F; };
 
     // ---- per-thread constants -----------------------------------------------------------------------------------------
     // weight stream: this thread's two 16-byte pieces of a slab
@@ -100,35 +119,39 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
     }
     const size_t tap_stride = (size_t)P.Cout * P.CinPad * 2;
     const char* wbase = reinterpret_cast<const char*>(P.wp);
-    // halo pieces: piece i = (u * 8 + wave) * 64 + lane -> LDS row i >> 3, position i & 7 (holds source chunk pos ^ (row & 7))
-    int hinfo[NU];                                        // iy | ix << 8 | patch << 16 | source chunk << 24 ; < 0: no piece
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int i = (u * 8 + wave) * 64 + lane, row = i >> 3, pos = i & 7;
-        const int patch = row / (IH * IW), rr = row - patch * (IH * IW);
-        const int iy = rr / IW, ix = rr - iy * IW;
-        hinfo[u] = (i < NPIECE) ? (iy | (ix << 8) | (patch << 16) | ((pos ^ (row & 7)) << 24)) : -1;
-    }
-    // fragment offsets: A = weight rows wc * 64 + tm * 16 + r; B = halo rows of this wave's 4 x 16 pixels
+    // input pieces: piece i = (u * 8 + wave) * 64 + lane -> LDS row i >> 3, position i & 7 (holds source chunk pos ^ (row & 7));
+    // recomputed from the lane id where needed (a handful of integer instructions per piece and K chunk) instead of held in registers
+    // (`l` = an OPAQUE copy of the lane id: without it the compiler hoists all of this out of the tile loop and spills it)
+    auto piece = [&](int u, int l, int& row, int& chunk) -> bool {
+        const int i = (u * 8 + wave) * 64 + l;
+        row = i >> 3; chunk = (i & 7) ^ (row & 7);
+        return i < NPIECE;
+    };
+    auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    const char* const zero_page = reinterpret_cast<const char*>(g_zero_page);
+    // fragment offsets: A = weight rows wc * 64 + tm * 16 + r; B = input rows of this wave's 4 x 16 pixels
     const int aoff = frag_off(wc * 64 + r, q);
-    int hpb[4], opix[4];                                  // halo row of the window's top-left corner / pixel offset inside the tile's frame block
+    int hpb[4];                                           // GEO 0: halo row of the window's top-left corner; whole frames: the pixel's row
+    int opix[4];                                          // pixel offset inside the tile
+    unsigned vmask[4];                                    // whole frames: bit tap = the tap's source pixel is inside the frame
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
-        if (PW == 16) {
+        if (!WF) {
             const int py = wpx * 4 + tn, px = r;
-            hpb[tn] = py * IW + px; opix[tn] = py * P.W + px;
+            hpb[tn] = py * IW + px; opix[tn] = py * P.W + px; vmask[tn] = 0x1FFu;
         } else {
-            // lanes r = 4..11 take one image row, r = 0..3 and 12..15 the next: each ds_read_b128 lane group then reads 8 consecutive
-            // halo rows per chunk position (distinct mod 8 -> conflict-free), which two rows of a 10-wide halo are not
-            const bool lo = (r >= 4) && (r < 12);
-            const int py = 2 * tn + (lo ? 0 : 1), px = lo ? r - 4 : (r < 4 ? r : r - 8);
-            hpb[tn] = wpx * (IH * IW) + py * IW + px; opix[tn] = wpx * (P.H * P.W) + py * P.W + px;
+            const int p = wpx * 64 + tn * 16 + r, y = (p / S) % S, x = p % S;
+            hpb[tn] = p; opix[tn] = p;
+            unsigned m = 0;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                m |= (yy >= 0 && yy < S && xx >= 0 && xx < S) ? (1u << tap) : 0u;
+            }
+            vmask[tn] = m;
         }
     }
-    float4 bias4[4];
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm)
-        bias4[tm] = P.bias ? *reinterpret_cast<const float4*>(P.bias + j * 128 + wc * 64 + tm * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 128) biasl[tid] = P.bias ? P.bias[j * 128 + tid] : 0.f;      // visible after the prologue's barriers
 
     // ---- helpers ------------------------------------------------------------------------------------------------------
     int pcc = 0, ptap = 0, pslot = 0;                     // weight prefetch cursor (wraps at the end of a tile: the stream repeats)
@@ -142,42 +165,61 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
     };
     unsigned okmask = 0;                                  // PRO: pieces of the buffer in flight that hold image pixels
     auto issue_halo = [&](int t, int cc, int buf) {
-        const int fg = t / tiles_pf, rem = t - fg * tiles_pf, ty = rem / tiles_x, tx = rem - ty * tiles_x;
-        const int f0 = fg * NP;
         const bool second = (cc << 6) >= P.C0;           // wave-uniform: which tensor of the concat this K chunk comes from
         const char* xb = reinterpret_cast<const char*>(second ? P.x1 : P.x0);
         const int Cs = second ? P.C1 : P.C0, cb = (cc << 6) - (second ? P.C0 : 0);
         const unsigned dst = __builtin_amdgcn_readfirstlane(halo_a + buf * HBUF + wave * 1024);
         okmask = 0;
+        const int l = opaque_lane();
+        if (WF) {
+            const unsigned pix0 = (unsigned)t * 256u;     // a tile = 256 consecutive pixel rows of the tensor (tensors < 4 GB: launcher)
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int hi = hinfo[u];
-            if (hi >= 0) {
-                const int gy = ty * PH - 1 + (hi & 255), gx = tx * PW - 1 + ((hi >> 8) & 255), f = f0 + ((hi >> 16) & 255);
-                const bool ok = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && f < P.NF;
-                const size_t off = ((size_t)((f * P.H + gy) * P.W + gx) * Cs + cb + ((hi >> 24) << 3)) * 2;
-                const void* src = ok ? static_cast<const void*>(xb + off) : static_cast<const void*>(g_zero_page);
-                glds16(src, dst + u * 8 * 1024);
-                okmask |= ok ? (1u << u) : 0u;
+            for (int u = 0; u < NU; ++u) {
+                int row, ch;
+                if (piece(u, l, row, ch)) {
+                    const bool ok = row < 256;            // row 256 = the zero row
+                    const unsigned off = ((pix0 + row) * Cs + cb + (ch << 3)) * 2u;
+                    const void* src = ok ? static_cast<const void*>(xb + off) : static_cast<const void*>(zero_page);
+                    glds16(src, dst + u * 8 * 1024);
+                    okmask |= ok ? (1u << u) : 0u;
+                }
+            }
+        } else {
+            const int f = t / tiles_pf, rem = t - f * tiles_pf, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                int row, ch;
+                if (piece(u, l, row, ch)) {
+                    const int iy = (row * 3641) >> 16, ix = row - iy * IW;        // row / 18 for row < 324
+                    const int gy = ty * 16 - 1 + iy, gx = tx * 16 - 1 + ix;
+                    const bool ok = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+                    const unsigned off = ((unsigned)((f * P.H + gy) * P.W + gx) * Cs + cb + (ch << 3)) * 2u;
+                    const void* src = ok ? static_cast<const void*>(xb + off) : static_cast<const void*>(zero_page);
+                    glds16(src, dst + u * 8 * 1024);
+                    okmask |= ok ? (1u << u) : 0u;
+                }
             }
         }
     };
-    // PRO: x_hat = SiLU(x * a[c] + d[c]) in place on this thread's piece u of halo buffer `buf` (zero padding stays zero)
+    // PRO: x_hat = SiLU(x * a[c] + d[c]) in place on this thread's piece u of input buffer `buf` (zero padding stays zero)
     auto transform = [&](int u, int cc, int buf) {
-        const int hi = hinfo[u];
-        if (hi < 0 || !((okmask >> u) & 1u)) return;
-        const int i = (u * 8 + wave) * 64 + lane;
-        char* p = halo + buf * HBUF + i * 16;
-        const int c = (cc << 6) + ((hi >> 24) << 3);
-        const uint4 v = *reinterpret_cast<const uint4*>(p);
-        const float4 a0 = *reinterpret_cast<const float4*>(coefA + c), a1 = *reinterpret_cast<const float4*>(coefA + c + 4);
-        const float4 d0 = *reinterpret_cast<const float4*>(coefD + c), d1 = *reinterpret_cast<const float4*>(coefD + c + 4);
-        uint4 o;
-        o.x = pack_bf16x2(silu_f(fmaf(__uint_as_float(v.x << 16), a0.x, d0.x)), silu_f(fmaf(__uint_as_float(v.x & 0xFFFF0000u), a0.y, d0.y)));
-        o.y = pack_bf16x2(silu_f(fmaf(__uint_as_float(v.y << 16), a0.z, d0.z)), silu_f(fmaf(__uint_as_float(v.y & 0xFFFF0000u), a0.w, d0.w)));
-        o.z = pack_bf16x2(silu_f(fmaf(__uint_as_float(v.z << 16), a1.x, d1.x)), silu_f(fmaf(__uint_as_float(v.z & 0xFFFF0000u), a1.y, d1.y)));
-        o.w = pack_bf16x2(silu_f(fmaf(__uint_as_float(v.w << 16), a1.z, d1.z)), silu_f(fmaf(__uint_as_float(v.w & 0xFFFF0000u), a1.w, d1.w)));
-        *reinterpret_cast<uint4*>(p) = o;
+        int row, ch;
+        const int l = opaque_lane();
+        if (!piece(u, l, row, ch) || !((okmask >> u) & 1u)) return;
+        char* p = halo + buf * HBUF + ((u * 8 + wave) * 64 + l) * 16;
+        const int c = (cc << 6) + (ch << 3);
+        // two halves of 4 channels, fenced, so that at most one half's operands (2 + 8 registers) are live beside the accumulators
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint2 v = *reinterpret_cast<const uint2*>(p + 8 * h);
+            const float4 a = *reinterpret_cast<const float4*>(coefA + c + 4 * h);
+            const float4 d = *reinterpret_cast<const float4*>(coefD + c + 4 * h);
+            uint2 o;
+            o.x = pack_bf16x2(silu_f(fmaf(__uint_as_float(v.x << 16), a.x, d.x)), silu_f(fmaf(__uint_as_float(v.x & 0xFFFF0000u), a.y, d.y)));
+            o.y = pack_bf16x2(silu_f(fmaf(__uint_as_float(v.y << 16), a.z, d.z)), silu_f(fmaf(__uint_as_float(v.y & 0xFFFF0000u), a.w, d.w)));
+            *reinterpret_cast<uint2*>(p + 8 * h) = o;
+            asm volatile("" ::: "memory");
+        }
     };
     // PRO: per-channel GroupNorm-apply (+ time scale/shift) coefficients of sample b (every thread calls; ends with a barrier)
     auto make_coef = [&](int b) {
@@ -211,14 +253,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
             }
         }
     };
+    // fragment loads.  B row of (tn, tap): GEO 0: the halo row under the tap; whole frames: the neighbouring pixel's row, or the zero row
+    auto ldA1 = [&](int sl, int tm, int ks) -> uint4 {
+        return *reinterpret_cast<const uint4*>(ring + sl * WS_SLAB + ((aoff + tm * 2048) ^ (ks * 64)));
+    };
+    auto ldB = [&](uint4 (&b)[4], const int (&hp)[4], int buf, int tap, int ks) {
+        const char* hb = halo + buf * HBUF;
+        const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn) {
+            int row;
+            if (WF) row = ((vmask[tn] >> tap) & 1u) ? hp[tn] + (dy - 1) * S + (dx - 1) : 256;
+            else row = hp[tn] + dy * IW + dx;
+            b[tn] = *reinterpret_cast<const uint4*>(hb + (frag_off(row, q) ^ (ks * 64)));
+        }
+    };
 
-    // ---- pipeline prologue: NS - 1 weight slabs and the first halo buffer ----------------------------------------------
+    // ---- pipeline prologue: NS - 1 weight slabs and the first input buffer ---------------------------------------------
     int bcoef = -1;
-    const int b0 = (t0 / tiles_pf) * NP / P.F;
+    const int b0 = sample_of(t0);
     if (PRO) { make_coef(b0); bcoef = b0; }
+    issue_halo(t0, 0, 0);
 #pragma unroll
     for (int k = 0; k < NS - 1; ++k) issue_w();
-    issue_halo(t0, 0, 0);
     wait_vm_lgkm0<0>();
     __builtin_amdgcn_s_barrier();
     if (PRO) {
@@ -230,50 +287,54 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
 
     int cslot = 0, hbuf = 0, bcur = b0;
     f32x4 acc[4][4];
-    // one K chunk = 9 taps on halo buffer hbuf; (tn_, ccn_) = the halo to fetch meanwhile.  AFTER_EPI: the 16 stores of the previous
-    // tile's epilogue sit between the weight slabs in flight, so the first three syncs leave that many more operations outstanding.
-    auto run_chunk = [&](auto after_epi, int cc, int tnext, int ccnext, bool xform) {
+    // fragments loaded one tap ahead (the sync of a tap guarantees the NEXT tap's slab): K step 0 of the 4 pixel tiles + the first
+    // weight tile, so the barrier is followed by MFMAs, not by LDS latency.  (Holding both K steps of both operands in registers,
+    // 64 of them, was measured slower: r02, spills.)
+    uint4 pb[4], pa;
+    ldB(pb, hpb, 0, 0, 0); pa = ldA1(0, 0, 0);
+    // one K chunk = 9 taps on input buffer hbuf; (tnext, ccnext) = the buffer to fetch meanwhile.  AFTER_EPI: the 16 stores of the
+    // previous tile's epilogue sit between the weight slabs in flight, so the first two syncs leave that many more operations outstanding.
+    auto run_chunk = [&](auto after_epi, int tnext, int ccnext, bool xform) {
         constexpr int EPI = decltype(after_epi)::value ? WS_STORES : 0;
         int hp[4];                                       // opaque copies: the 36 per-tap fragment offsets are recomputed (3 VALU each)
 #pragma unroll                                           // instead of being hoisted out of the tile loop into 36 live registers
         for (int tn = 0; tn < 4; ++tn) { hp[tn] = hpb[tn]; asm volatile("" : "+v"(hp[tn])); }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            // sync: slab (cc, tap) has landed in every wave's view; every wave is done with slab (cc, tap - 1) and, at tap 0, with the other halo buffer
+            // sync of tap: every wave's part of slab (tap + 1) has landed (issued two taps ago; at most the younger slab, and at taps
+            // 0 / 1 the input pieces and the epilogue stores, may still be in flight), every wave is done with slab (tap - 1) and, at
+            // tap 0, with the other input buffer; at tap 2 the input pieces issued at tap 0 (older than slab 3) have landed too
             if (tap == 0) wait_vm_lgkm0<WIN + EPI>();
-            else if (tap <= 2) wait_vm_lgkm0<WIN + NUMIN + EPI>();
-            else if (tap == 3) wait_vm_lgkm0<WIN + NUMIN>();
+            else if (tap == 1) wait_vm_lgkm0<WIN + NUMIN + EPI>();
             else wait_vm_lgkm0<WIN>();
             __builtin_amdgcn_s_barrier();
-            issue_w();
             if (tap == 0) issue_halo(tnext, ccnext, hbuf ^ 1);
-            if (PRO && xform) {                          // own pieces, landed since the sync of tap 4; spread over the remaining taps
-                if (tap == 5) { transform(0, ccnext, hbuf ^ 1); transform(1, ccnext, hbuf ^ 1); }
-                if (tap == 6) { transform(2, ccnext, hbuf ^ 1); transform(3, ccnext, hbuf ^ 1); }
-                if (tap == 7) {
+            issue_w();
+            // K step 0 on the prefetched fragments (MFMAs right behind the barrier), then K step 1, then the next tap's prefetch
 #pragma unroll
-                    for (int u = 4; u < NU; ++u) transform(u, ccnext, hbuf ^ 1);
+            for (int tm = 0; tm < 4; ++tm) {
+                const uint4 a = tm == 0 ? pa : ldA1(cslot, tm, 0);
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) M::mma(acc[tm][tn], a, pb[tn]);
+            }
+            if (PRO && xform && tap >= 2 && tap - 2 < NU) {      // own pieces, landed since the sync of tap 2: one per tap, done by tap 7
+                transform(tap - 2, ccnext, hbuf ^ 1);
+                if (NU > 6 && tap == 7) transform(6, ccnext, hbuf ^ 1);
+            }
+            {
+                uint4 b1[4];
+                ldB(b1, hp, hbuf, tap, 1);
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+                    const uint4 a = ldA1(cslot, tm, 1);
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) M::mma(acc[tm][tn], a, b1[tn]);
                 }
             }
-            const int dy = tap / 3, dx = tap - 3 * dy;
-            const char* ws = ring + cslot * WS_SLAB;
-            const char* hb = halo + hbuf * HBUF;
-            int boff[4];
-#pragma unroll
-            for (int tn = 0; tn < 4; ++tn) boff[tn] = frag_off(hp[tn] + dy * IW + dx, q);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                uint4 af[4], bf[4];
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm) af[tm] = *reinterpret_cast<const uint4*>(ws + ((aoff + tm * 2048) ^ (ks * 64)));
-#pragma unroll
-                for (int tn = 0; tn < 4; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(hb + (boff[tn] ^ (ks * 64)));
-#pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
-#pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
-            }
-            if (++cslot == NS) cslot = 0;
+            const int nslot = (cslot + 1 == NS) ? 0 : cslot + 1;
+            ldB(pb, hp, tap == 8 ? hbuf ^ 1 : hbuf, tap == 8 ? 0 : tap + 1, 0);
+            pa = ldA1(nslot, 0, 0);
+            cslot = nslot;
         }
         hbuf ^= 1;
     };
@@ -285,33 +346,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
 #pragma unroll
             for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int cc = 0; cc < nchunks; ++cc) {
-            // the halo to fetch during this chunk (the very last fetch re-reads a valid tile into the idle buffer: the counted
+            // the buffer to fetch during this chunk (the very last fetch re-reads a valid tile into the idle buffer: the counted
             // waits assume the same instruction sequence in every chunk)
             const bool last = (cc + 1 == nchunks);
             const bool more = !last || (t + 1 < t1);
             const int tnext = last ? (t + 1 < t1 ? t + 1 : t) : t, ccnext = last ? 0 : cc + 1;
             if (PRO && more) {
-                const int bn = (tnext / tiles_pf) * NP / P.F;
+                const int bn = sample_of(tnext);
                 if (bn != bcoef) { make_coef(bn); bcoef = bn; }      // uniform; the tables are only read by transform() below
             }
-            if (after_epilogue) run_chunk(std::true_type{}, cc, tnext, ccnext, more);
-            else run_chunk(std::false_type{}, cc, tnext, ccnext, more);
+            if (after_epilogue) run_chunk(std::true_type{}, tnext, ccnext, more);
+            else run_chunk(std::false_type{}, tnext, ccnext, more);
             after_epilogue = false;
         }
         // ---- epilogue of tile t: +bias, store, statistics --------------------------------------------------------------
         {
-            const int fg = t / tiles_pf, rem = t - fg * tiles_pf, ty = rem / tiles_x, tx = rem - ty * tiles_x;
-            const int b = fg * NP / P.F;
+            const int b = sample_of(t);
             if (b != bcur) { flush_stats(bcur); bcur = b; }
-            const size_t tile_pix = ((size_t)fg * NP * P.H + (size_t)ty * PH) * P.W + (size_t)tx * PW;
+            size_t tile_pix;
+            if (WF) tile_pix = (size_t)t * 256;
+            else { const int f = t / tiles_pf, rem = t - f * tiles_pf, ty = rem / tiles_x, tx = rem - ty * tiles_x;
+                   tile_pix = ((size_t)f * P.H + (size_t)ty * 16) * P.W + (size_t)tx * 16; }
             const int cobase = j * 128 + wc * 64 + 4 * q;
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) {
                 float s = 0.f, ss = 0.f;
+                const float4 bs = *reinterpret_cast<const float4*>(biasl + wc * 64 + tm * 16 + 4 * q);
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) {
-                    const float4 v = make_float4(acc[tm][tn][0] + bias4[tm].x, acc[tm][tn][1] + bias4[tm].y,
-                                                 acc[tm][tn][2] + bias4[tm].z, acc[tm][tn][3] + bias4[tm].w);
+                    const float4 v = make_float4(acc[tm][tn][0] + bs.x, acc[tm][tn][1] + bs.y, acc[tm][tn][2] + bs.z, acc[tm][tn][3] + bs.w);
                     const size_t e = (tile_pix + opix[tn]) * P.Cout + cobase + tm * 16;
                     if (P.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.y) + e * 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
                     else *reinterpret_cast<float4*>(P.y + e) = v;
@@ -329,6 +392,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
 
 // ---- host side ----------------------------------------------------------------------------------------------------------
 
+static int ws_geo(const ConvArgs& a) {                    // 0: 16 x 16 tiles, 8 / 16: whole frames, -1: not served
+    if (a.H == 8 && a.W == 8 && a.F % 4 == 0) return 8;
+    if (a.H == 16 && a.W == 16) return 16;
+    if (a.H % 16 == 0 && a.W % 16 == 0) return 0;
+    return -1;
+}
+
 bool conv3x3_ws_eligible(int mode, const ConvArgs& a) {
     if (mode != MODE_BF16 || a.kind != 0 || a.kh != 3 || a.kw != 3 || a.stride != 1 || a.res) return false;
     if (!a.x0_bf16 || (a.C1 && !a.x1_bf16)) return false;
@@ -336,21 +406,20 @@ bool conv3x3_ws_eligible(int mode, const ConvArgs& a) {
     const int nct = a.Cout / 128;
     if (nct != 1 && nct != 2 && nct != 4 && nct != 8) return false;
     if (a.wrows != a.Cout || a.wrow0 != 0) return false;
-    const bool sq16 = (a.H % 16 == 0) && (a.W % 16 == 0);
-    const bool sq8 = (a.H == 8 && a.W == 8 && a.NF % 4 == 0 && a.F % 4 == 0);
-    if (!sq16 && !sq8) return false;
+    const int geo = ws_geo(a);
+    if (geo < 0) return false;
     if (a.pro && (a.C1 || a.groups < 1 || a.groups > 32 || a.C0 % a.groups || a.C0 > 1024)) return false;
     if (a.out_stats && (a.out_groups < 1 || a.Cout % a.out_groups || (a.Cout / a.out_groups) % 16)) return false;
-    const long tiles = sq16 ? (long)a.NF * (a.H / 16) * (a.W / 16) : a.NF / 4;
+    const long tiles = geo == 0 ? (long)a.NF * (a.H / 16) * (a.W / 16) : (long)a.NF * a.H * a.W / 256;
     if (tiles * nct < 128) return false;                 // too few tiles to feed the chip from persistent workgroups: generic kernel
-    if ((size_t)a.NF * a.H * a.W * (size_t)std::max(a.C0, a.C1) * 2 >= (1ull << 40)) return false;
+    if ((size_t)a.NF * a.H * a.W * (size_t)std::max(a.C0, a.C1) * 2 >= 0xFFFF0000ull) return false;     // 32-bit byte offsets
     return true;
 }
 
 hipError_t launch_conv3x3_ws(const ConvArgs& a, hipStream_t st) {
-    const bool sq16 = (a.H % 16 == 0) && (a.W % 16 == 0);
+    const int geo = ws_geo(a);
     const int nct = a.Cout / 128;
-    const int total = sq16 ? a.NF * (a.H / 16) * (a.W / 16) : a.NF / 4;
+    const int total = geo == 0 ? a.NF * (a.H / 16) * (a.W / 16) : (int)((long)a.NF * a.H * a.W / 256);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
     const int unit = 8 * nct;                             // the decode deals ranges to the 8 XCDs
@@ -358,9 +427,8 @@ hipError_t launch_conv3x3_ws(const ConvArgs& a, hipStream_t st) {
     grid = std::min(grid, (total * nct + unit - 1) / unit * unit);
     const int nranges = grid / nct;
     const int tpr = (total + nranges - 1) / nranges;
-    const int NS = sq16 ? 4 : 3;
-    const int HPX = sq16 ? 18 * 18 : 4 * 10 * 10;
-    const size_t lds = (size_t)NS * WS_SLAB + 2 * (size_t)HPX * 128 + (a.pro ? (size_t)a.CinPad * 8 + 256 : 0);
+    const int HPX = geo == 0 ? 18 * 18 : 257;
+    const size_t lds = (size_t)WS_NS * WS_SLAB + 2 * (size_t)HPX * 128 + 512 + (a.pro ? (size_t)a.CinPad * 8 + 256 : 0);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     auto go = [&](auto kfn) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -368,8 +436,9 @@ hipError_t launch_conv3x3_ws(const ConvArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a, tpr, total, nct);
         return hipGetLastError();
     };
-    if (sq16) return a.pro ? go(conv3x3_ws_kernel<16, 4, true>) : go(conv3x3_ws_kernel<16, 4, false>);
-    return a.pro ? go(conv3x3_ws_kernel<8, 3, true>) : go(conv3x3_ws_kernel<8, 3, false>);
+    if (geo == 0) return a.pro ? go(conv3x3_ws_kernel<0, true>) : go(conv3x3_ws_kernel<0, false>);
+    if (geo == 8) return a.pro ? go(conv3x3_ws_kernel<8, true>) : go(conv3x3_ws_kernel<8, false>);
+    return a.pro ? go(conv3x3_ws_kernel<16, true>) : go(conv3x3_ws_kernel<16, false>);
 }
 
 }  // namespace vdx
