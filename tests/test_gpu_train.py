@@ -63,3 +63,19 @@ def test_short_training_run_decreases_loss(tmp_path):
     assert len(losses) == 30 and all(np.isfinite(losses))
     assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), (losses[:5], losses[-5:])
     assert tr.ckpt_manager.all_steps()[-1] == 30 and torch.isfinite(unet.flat_params).all()
+
+
+def test_device_prefetcher_pinned_side_stream():
+    """DevicePrefetcher on the GPU: pinned staging buffers, copies on a side stream, the consumer's stream waits on
+    the copy event; every batch arrives intact and in order while the consumer keeps the device busy."""
+    from video_diffusion_nnx_amd.datasets import DevicePrefetcher
+    g = torch.Generator().manual_seed(0)
+    batches = [torch.rand(4, 1, 4, 16, 16, generator=g) for _ in range(6)]
+    pf = DevicePrefetcher(iter(batches), 'cuda', select=lambda b: b[2:4])
+    assert pf.on_gpu and pf._pinned[0].is_pinned()
+    busy = torch.zeros(1 << 22, device='cuda')
+    for i, dev in enumerate(pf):
+        busy += 1.0                                            # keep the compute stream occupied between batches
+        assert dev.is_cuda and dev.shape == (2, 1, 4, 16, 16)
+        assert torch.equal(dev.cpu(), batches[i][2:4])
+    assert i == 5

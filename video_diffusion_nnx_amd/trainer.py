@@ -201,10 +201,12 @@ class Trainer:
         assert callable(log_fn)
         logging.info(f'Starting training loop from step {self.step}...')
         import torch.distributed as dist
+        from .datasets import DevicePrefetcher
+        lo, hi = self.rank * self.per_device_bs, (self.rank + 1) * self.per_device_bs
+        # this rank's shard of every batch (P('data', None), trainer.py:309), staged one batch ahead on a side stream
+        shards = DevicePrefetcher(self.dl, self.device, select=lambda b: b[lo:hi])
         while self.step < self.train_num_steps:
-            batch = next(self.dl)
-            batch = torch.as_tensor(np.asarray(batch))
-            shard = batch[self.rank * self.per_device_bs:(self.rank + 1) * self.per_device_bs]     # P('data', None) (trainer.py:309)
+            shard = next(shards)
             t0 = time.time()
             loss = self.train_step(shard, self.step)
             if self.dist_on and self.world > 1:                  # global mean loss = mean of equal-size shard means (C2)
