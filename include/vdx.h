@@ -217,6 +217,33 @@ int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, fl
                       uint64_t* step_dev, const float* tables, int timesteps, int nsteps, const float* cond, uint64_t seed,
                       int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream);
 
+/* Dynamic thresholding of p_mean_variance (gaussian_diffusion.py:205-217): s[b] = max(quantile(|x0_hat_b|, percentile), 1) with
+ * x0_hat = predict_start_from_noise(x, t, eps_hat) and the linearly interpolated quantile (jnp.quantile default).  tables as in
+ * vdx_p_sample_step (rows 0 and 1 are used).  thres_out [B]. */
+int vdx_dynamic_threshold(const float* x, const float* eps_hat, const int* t, const float* tables, int timesteps, float percentile,
+                          float* thres_out, int batch, int channels, long per_sample, void* stream);
+
+/* vdx_p_sample_loop with use_dynamic_thres (gaussian_diffusion.py:205-217) inside the captured step: thres_buf [B] floats scratch,
+ * percentile in (0, 1].  percentile <= 0 is exactly vdx_p_sample_loop. */
+int vdx_p_sample_loop_dyn(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
+                          uint64_t* step_dev, const float* tables, int timesteps, int nsteps, const float* cond, uint64_t seed,
+                          int clip_denoised, float percentile, float* thres_buf, void* workspace, size_t workspace_bytes, int batch,
+                          int use_graph, void* stream);
+
+/* DDIM sampling, eta = 0 (EXTENSION: the reference has ancestral DDPM sampling only; BASELINE.json configs[3] names "DDIM-100").
+ * One step: x0 = (x - sqrt(1-ac_t) eps) / sqrt(ac_t), clipped like p_sample; eps' re-derived from the clipped x0;
+ * out = sqrt(ac_next) x0 + sqrt(1-ac_next) eps'.  seq: device int32 [n + 1] = the time sequence t_0 > t_1 > ... > t_{n-1}, -1
+ * (-1 = the data, alpha_bar 1); step k uses (seq[k], seq[k+1]) with k = *step_dev (device uint64) or 0 when step_dev is NULL.
+ * alphas_cumprod: device fp32 [T].  x and out may alias. */
+int vdx_ddim_step(const float* x, const float* eps_hat, float* out, const float* alphas_cumprod, const int* seq,
+                  const uint64_t* step_dev, const float* thres, int clip_denoised, int batch, int channels, long per_sample, void* stream);
+
+/* The DDIM loop: nsteps x { Unet3D forward at t = seq[k] ; vdx_ddim_step ; t = max(seq[k+1], 0), k += 1 }, captured once in a
+ * hipGraph like vdx_p_sample_loop.  t_dev [B] must hold seq[0] and *step_dev 0 on entry; seq_len = n (seq has n + 1 entries). */
+int vdx_ddim_sample_loop(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
+                         uint64_t* step_dev, const float* alphas_cumprod, const int* seq, int seq_len, int nsteps, const float* cond,
+                         int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Backward building blocks (autodiff of the forward operators; reference trainer.py:361 jax.value_and_grad).
  * ---------------------------------------------------------------------------------------------- */

@@ -151,6 +151,27 @@ class DiffusionRef:
             img = self.p_sample(img, t, noises[n])
         return (img + 1) * 0.5
 
+    def ddim_sample_loop(self, x_T, steps: int, clip_denoised: bool = True):
+        """DDIM, eta = 0 (Song, Meng & Ermon 2020, eq. 12) over the evenly spaced sub-sequence linspace(-1, T-1, steps+1).
+        PARITY UNPINNED: the reference has no DDIM sampler (gaussian_diffusion.py:264-320 is ancestral DDPM only); this is the closed
+        form restated from the paper, used to check the HIP step (BASELINE.json configs[3]).  Returns x_0 in [-1, 1]."""
+        import numpy as _np
+        times = _np.linspace(-1, self.num_timesteps - 1, steps + 1).astype(_np.int64)[::-1]
+        ac = self.tab['alphas_cumprod']
+        x = x_T.to(ac.dtype)
+        b = x.shape[0]
+        for k in range(steps):
+            t, tn = int(times[k]), int(times[k + 1])
+            eps = self.denoise(x, torch.full((b,), t, dtype=torch.long)).permute(0, 4, 1, 2, 3)
+            a_t = ac[t]
+            a_n = ac[tn] if tn >= 0 else torch.ones((), dtype=ac.dtype)
+            x0 = (x - (1 - a_t).sqrt() * eps) / a_t.sqrt()
+            if clip_denoised:
+                x0 = x0.clamp(-1.0, 1.0)
+            eps2 = (x - a_t.sqrt() * x0) / (1 - a_t).sqrt()
+            x = a_n.sqrt() * x0 + (1 - a_n).sqrt() * eps2
+        return x
+
     # -- training loss -----------------------------------------------------------------------
     def p_losses(self, x_start, t, noise, eps_pred=None):
         x_noisy = self.q_sample(x_start, t, noise)

@@ -151,3 +151,92 @@ def test_dynamic_threshold_path():
     ref = DiffusionRef(lambda a, b: R.unet_forward(p, cfg, a, b), image_size=8, num_frames=2, channels=1, timesteps=4,
                        use_dynamic_thres=True, dtype=torch.float64)
     np.testing.assert_allclose(gd.p_sample(x, t, key=None, noise=z).cpu().double(), ref.p_sample(x.double(), t, z.double()), atol=1e-4)
+
+
+# ---- DDIM (extension, BASELINE.json configs[3]; PARITY UNPINNED: no reference code, checked against the paper's closed form) ----
+
+def test_ddim_step_elementwise_and_sequence():
+    from video_diffusion_nnx_amd import _lib as L
+    from video_diffusion_nnx_amd.gaussian_diffusion import ddim_time_sequence, make_tables, vdx_ddim_step
+    seq = ddim_time_sequence(1000, 100)
+    assert seq[0] == 999 and seq[-1] == -1 and len(seq) == 101 and (np.diff(seq) < 0).all() and seq[-2] >= 0
+    assert list(ddim_time_sequence(10, 10)) == [9, 8, 7, 6, 5, 4, 3, 2, 1, 0, -1]
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(3)
+    B, C, per = 3, 2, 2 * 4 * 8 * 8
+    x = torch.randn(B, C, 4, 8, 8, generator=g)
+    eps = torch.randn(B, 4, 8, 8, C, generator=g)
+    ac = torch.from_numpy(make_tables(1000)['alphas_cumprod'])
+    seqd = torch.from_numpy(seq).to(dev)
+    for k in (0, 57, 99):                                     # first, middle, last (t_next = -1: the data itself)
+        step = torch.full((1,), k, dtype=torch.int64, device=dev)
+        out = torch.empty(B, C, 4, 8, 8, device=dev)
+        L.check(vdx_ddim_step(L.ptr(x.to(dev)), L.ptr(eps.to(dev)), L.ptr(out), L.ptr(ac.to(dev)), L.ptr(seqd), L.ptr(step), 0, 1, B, C, per,
+                              L.stream_ptr()))
+        t, tn = int(seq[k]), int(seq[k + 1])
+        a_t, a_n = ac[t].double(), (ac[tn].double() if tn >= 0 else torch.tensor(1.0, dtype=torch.float64))
+        e = eps.permute(0, 4, 1, 2, 3).double()
+        x0 = ((x.double() - (1 - a_t).sqrt() * e) / a_t.sqrt()).clamp(-1, 1)
+        ref = a_n.sqrt() * x0 + (1 - a_n).sqrt() * (x.double() - a_t.sqrt() * x0) / (1 - a_t).sqrt()
+        assert (out.cpu().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), k
+        if tn < 0:
+            assert (out.cpu().double() - x0).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('use_graph', [True, False])
+def test_ddim_sample_loop_matches_oracle(use_graph):
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    kw = dict(dim=16, channels=1, dim_mults=(1, 2))
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=2, dtype=torch.float64)
+    unet = Unet3D(rngs=0, mode='f32', **kw)
+    unet.load_state_dict({k: v.float() for k, v in p.items()})
+    T, S, shape = 60, 12, (2, 1, 4, 8, 8)
+    gd = GaussianDiffusion(unet, image_size=8, num_frames=4, channels=1, timesteps=T)
+    out = gd.ddim_sample_loop(shape, 11, steps=S, use_graph=use_graph)
+    n = int(np.prod(shape))
+    x_T = torch.from_numpy(philox_ref.randn(n, 11, 0)).double().reshape(shape)
+    ref = DiffusionRef(lambda a, b: R.unet_forward(p, cfg, a, b), image_size=8, num_frames=4, channels=1, timesteps=T, dtype=torch.float64)
+    exp = (ref.ddim_sample_loop(x_T, S) + 1) * 0.5
+    err = (out.cpu().double() - exp).abs().max().item()
+    assert err < 5e-4, err
+    again = gd.sample(11, batch_size=2, ddim_steps=S, use_graph=use_graph)       # deterministic given the seed; reuses the cached graph
+    assert torch.equal(again, out)
+
+
+def test_dynamic_threshold_quantile_and_graph_loop():
+    """use_dynamic_thres (gaussian_diffusion.py:205-217): the HIP radix-select quantile vs torch.quantile (linear interpolation, as
+    jnp.quantile), then the whole loop with the threshold inside the captured step vs the oracle's loop."""
+    from video_diffusion_nnx_amd import _lib as L
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion, vdx_dynamic_threshold
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    dev = torch.device('cuda:0')
+    kw = dict(dim=16, channels=3, dim_mults=(1, 2))
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=4, dtype=torch.float64)
+    unet = Unet3D(rngs=0, mode='f32', **kw)
+    unet.load_state_dict({k: v.float() for k, v in p.items()})
+    T = 12
+    gd = GaussianDiffusion(unet, image_size=8, num_frames=5, channels=3, timesteps=T, use_dynamic_thres=True, dynamic_thres_percentile=0.9)
+    g = torch.Generator().manual_seed(8)
+    B = 3
+    x = 2.5 * torch.randn(B, 3, 5, 8, 8, generator=g)
+    eps = torch.randn(B, 5, 8, 8, 3, generator=g)
+    t = torch.tensor([0, 5, 11], dtype=torch.int32)
+    for q in (0.9, 0.5, 1.0, 0.123):
+        s = torch.empty(B, device=dev)
+        L.check(vdx_dynamic_threshold(L.ptr(x.to(dev)), L.ptr(eps.to(dev)), L.ptr(t.to(dev)), L.ptr(gd._ptab), T, q, L.ptr(s), B, 3, 3 * 5 * 64,
+                                      L.stream_ptr()))
+        xr = gd.predict_start_from_noise(x.to(dev), t.to(dev), eps.to(dev).permute(0, 4, 1, 2, 3)).cpu()
+        ref = torch.quantile(xr.abs().reshape(B, -1), q, dim=-1).clamp_min(1.0)
+        assert torch.allclose(s.cpu(), ref, rtol=1e-6, atol=1e-6), (q, s.cpu(), ref)
+    shape = (2, 3, 5, 8, 8)
+    out = gd.p_sample_loop(shape, 5)
+    n = int(np.prod(shape))
+    refd = DiffusionRef(lambda a, b: R.unet_forward(p, cfg, a, b), image_size=8, num_frames=5, channels=3, timesteps=T,
+                        use_dynamic_thres=True, dynamic_thres_percentile=0.9, dtype=torch.float64)
+    exp = refd.p_sample_loop(torch.from_numpy(philox_ref.randn(n, 5, 0)).double().reshape(shape),
+                             [torch.from_numpy(philox_ref.randn(n, 5, 1 + k)).double().reshape(shape) for k in range(T)])
+    err = (out.cpu().double() - exp).abs().max().item()
+    assert err < 1e-3, err

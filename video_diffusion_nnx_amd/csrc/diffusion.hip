@@ -121,6 +121,89 @@ __global__ __launch_bounds__(256) void p_sample_kernel(PSampleArgs P) {
     }
 }
 
+// DDIM reverse step, eta = 0 (Song et al. 2020, eq. 12; NO reference code: the reference samples with ancestral DDPM only --
+// BASELINE.json configs[3] asks for "DDIM-100").  Time pair (t, t_next) = (seq[k], seq[k+1]) with k = *step_dev
+// (or 0); t_next < 0 means "the data itself" (alpha_bar = 1).
+//   x0 = (x - sqrt(1 - ac_t) eps) / sqrt(ac_t)        [clip to +-s, / s as p_sample does]
+//   eps' = (x - sqrt(ac_t) x0) / sqrt(1 - ac_t)       (re-derived from the CLIPPED x0, as the usual implementations do)
+//   out = sqrt(ac_next) x0 + sqrt(1 - ac_next) eps'
+__global__ __launch_bounds__(256) void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, float* __restrict__ out,
+                                                        const float* __restrict__ ac, const int* __restrict__ seq,
+                                                        const unsigned long long* __restrict__ step_dev, const float* __restrict__ thres,
+                                                        int clip, int C, long per_sample) {
+    const int b = blockIdx.y;
+    const int k = step_dev ? (int)*step_dev : 0;
+    const int tb = seq[k], tn = seq[k + 1];
+    const float a_t = ac[tb], a_n = tn >= 0 ? ac[tn] : 1.0f;
+    const float sa = sqrtf(a_t), s1 = sqrtf(1.0f - a_t), na = sqrtf(a_n), n1 = sqrtf(1.0f - a_n);
+    const float s = thres ? thres[b] : 1.0f;
+    const long per = per_sample, fhw = per_sample / C;
+    const size_t base = (size_t)b * per;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < per; e += (long)gridDim.x * blockDim.x) {
+        const float xv = x[base + e];
+        const long c = e / fhw, r = e - c * fhw;                         // [C,F,H,W] -> channel-last [F,H,W,C]
+        const float ev = eps[base + r * C + c];
+        float x0 = (xv - s1 * ev) / sa;
+        if (clip) x0 = fminf(fmaxf(x0, -s), s) / s;
+        const float e2 = (xv - sa * x0) / s1;
+        out[base + e] = na * x0 + n1 * e2;
+    }
+}
+
+// after a DDIM step: t[b] = max(seq[k + 1], 0) for the next forward, k += 1
+__global__ void ddim_advance_kernel(int* t, int B, const int* __restrict__ seq, unsigned long long* step_dev) {
+    const int k = (int)*step_dev;
+    const int tn = max(seq[k + 1], 0);
+    for (int i = threadIdx.x; i < B; i += blockDim.x) t[i] = tn;
+    __syncthreads();
+    if (threadIdx.x == 0) *step_dev = (unsigned long long)(k + 1);
+}
+
+// Dynamic thresholding (Imagen; reference gaussian_diffusion.py:205-217): s_b = max(quantile_q(|x0_hat| over the sample), 1) with
+// x0_hat = sqrt_recip_ac[t] x - sqrt_recipm1_ac[t] eps and the linearly interpolated quantile of jnp.quantile / torch.quantile
+// (position q (n - 1)).  One workgroup per sample; the two order statistics are found by an exact 4 x 8-bit radix select on the
+// bit patterns of the (non-negative) magnitudes, recomputing x0_hat in every pass instead of storing it.
+__global__ __launch_bounds__(1024) void dyn_thres_kernel(const float* __restrict__ x, const float* __restrict__ eps, const int* __restrict__ t,
+                                                         const float* __restrict__ tables, int T, float q, float* __restrict__ out,
+                                                         int C, long per_sample) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel_prefix, sel_rank;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tb = t[b];
+    const float kr = tables[tb], km = tables[T + tb];
+    const long per = per_sample, fhw = per_sample / C;
+    const size_t base = (size_t)b * per;
+    const double pos = (double)q * (double)(per - 1);
+    const long k_lo = (long)floor(pos);
+    const long k_hi = min(k_lo + 1, per - 1);
+    const float frac = (float)(pos - (double)k_lo);
+    float val[2];
+    for (int which = 0; which < 2; ++which) {
+        unsigned prefix = 0, rank = (unsigned)(which ? k_hi : k_lo);      // rank of the wanted element among those matching `prefix`
+        for (int pass = 0; pass < 4; ++pass) {
+            const int shift = 24 - 8 * pass;
+            for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+            __syncthreads();
+            for (long e = tid; e < per; e += blockDim.x) {
+                const long c = e / fhw, r = e - c * fhw;
+                const unsigned u = __float_as_uint(fabsf(kr * x[base + e] - km * eps[base + r * C + c]));
+                if (pass == 0 || (u >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned acc = 0, d = 0;
+                for (; d < 256; ++d) { if (acc + hist[d] > rank) break; acc += hist[d]; }
+                sel_prefix = prefix | (d << shift); sel_rank = rank - acc;
+            }
+            __syncthreads();
+            prefix = sel_prefix; rank = sel_rank;
+            __syncthreads();
+        }
+        val[which] = __uint_as_float(prefix);
+    }
+    if (tid == 0) out[b] = fmaxf(val[0] + frac * (val[1] - val[0]), 1.0f);
+}
+
 __global__ void advance_kernel(int* t, int B, unsigned long long* dev_offset) {
     for (int i = threadIdx.x; i < B; i += blockDim.x)         // one workgroup strides over the batch (any B)
         if (t[i] > 0) t[i] -= 1;
@@ -172,6 +255,23 @@ hipError_t launch_p_sample(const PSampleArgs& a, int B, hipStream_t st) {
 
 hipError_t launch_advance(int* t, int B, unsigned long long* dev_offset, hipStream_t st) {
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1024), 0, st, t, B, dev_offset);
+    return hipGetLastError();
+}
+
+hipError_t launch_ddim_step(const float* x, const float* eps, float* out, const float* ac, const int* seq, const unsigned long long* step_dev,
+                            const float* thres, int clip, int B, int C, long per_sample, hipStream_t st) {
+    hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_blocks(per_sample), B), dim3(256), 0, st, x, eps, out, ac, seq, step_dev, thres, clip, C, per_sample);
+    return hipGetLastError();
+}
+
+hipError_t launch_ddim_advance(int* t, int B, const int* seq, unsigned long long* step_dev, hipStream_t st) {
+    hipLaunchKernelGGL(ddim_advance_kernel, dim3(1), dim3(256), 0, st, t, B, seq, step_dev);
+    return hipGetLastError();
+}
+
+hipError_t launch_dyn_thres(const float* x, const float* eps, const int* t, const float* tables, int T, float q, float* out, int B, int C,
+                            long per_sample, hipStream_t st) {
+    hipLaunchKernelGGL(dyn_thres_kernel, dim3(B), dim3(1024), 0, st, x, eps, t, tables, T, q, out, C, per_sample);
     return hipGetLastError();
 }
 

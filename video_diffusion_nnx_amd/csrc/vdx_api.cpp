@@ -7,10 +7,16 @@
 
 struct vdx_handle {
     vdx::Model model;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    // every argument the captured step bakes in (full pointers: two workspaces / streams never alias one key)
-    struct GraphKey { const void* p[10]; unsigned long long seed; int i[4]; size_t ws; } graph_key;
+    // every argument a captured sampling step bakes in (full pointers: two workspaces / streams never alias one key)
+    struct GraphKey { const void* p[12]; unsigned long long seed; int i[4]; size_t ws; float f; };
+    // one cached graph per loop kind: 0 = DDPM p_sample_loop, 1 = DDIM
+    struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; GraphKey key; } gs[2];
+    void drop_graphs() {
+        for (GraphSlot& g : gs) {
+            if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+            if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+        }
+    }
     vdx::BwdState bwd;
 };
 
@@ -23,6 +29,34 @@ int vdx_set_error(int code, const char* msg, const char* file, int line) {
 #define VDX_FAIL(code, msg) return vdx_set_error((code), (msg), __FILE__, __LINE__)
 #define VDX_HIP(expr)                                                                   \
     do { hipError_t _e = (expr); if (_e != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(_e), __FILE__, __LINE__); } while (0)
+
+// runs `step` nsteps times on `st`: eagerly, or (use_graph) captured once into the handle's graph slot `which` and replayed
+template <class Step>
+static int run_steps(vdx_handle* h, int which, const vdx_handle::GraphKey& key, int nsteps, int use_graph, hipStream_t st, Step step) {
+    if (!use_graph) {
+        for (int i = 0; i < nsteps; ++i) { int rc = step(); if (rc != VDX_OK) return rc; }
+        return VDX_OK;
+    }
+    vdx_handle::GraphSlot& g = h->gs[which];
+    int done = 0;
+    if (!g.exec || memcmp(&key, &g.key, sizeof(key)) != 0) {
+        if (nsteps == 0) return VDX_OK;
+        int rc = step();                                    // eager first step (also sets kernel attributes before capture)
+        if (rc != VDX_OK) return rc;
+        done = 1;
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+        VDX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = step();
+        hipError_t ce = hipStreamEndCapture(st, &g.graph);
+        if (rc != VDX_OK) return rc;
+        if (ce != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(ce), __FILE__, __LINE__);
+        VDX_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        g.key = key;
+    }
+    for (int i = done; i < nsteps; ++i) VDX_HIP(hipGraphLaunch(g.exec, st));
+    return VDX_OK;
+}
 
 extern "C" {
 
@@ -188,8 +222,7 @@ int vdx_create(const vdx_config* cfg, vdx_handle** out) {
 
 void vdx_destroy(vdx_handle* h) {
     if (!h) return;
-    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
-    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->drop_graphs();
     if (h->model.d_ss_layers) (void)hipFree(h->model.d_ss_layers);
     if (h->model.d_pack_jobs) (void)hipFree(h->model.d_pack_jobs);
     if (h->model.d_pack_t_jobs) (void)hipFree(h->model.d_pack_t_jobs);
@@ -201,8 +234,7 @@ int vdx_set_activation_storage(vdx_handle* h, int bf16) {
     if (bf16 && h->model.mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bf16 activation storage needs a VDX_MODE_BF16 handle");
     const int v = bf16 ? 1 : 0;
     if (v != h->model.act16) {                       // a cached sampling graph was captured with the other storage
-        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-        if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
+        h->drop_graphs();
         h->model.act16 = v;
     }
     return VDX_OK;
@@ -300,12 +332,23 @@ int vdx_affine(const float* x, float* y, long n, float a, float b, void* stream)
     return VDX_OK;
 }
 
-int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
-                      uint64_t* step_dev, const float* tables, int timesteps, int nsteps, const float* cond, uint64_t seed,
-                      int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream) {
+int vdx_dynamic_threshold(const float* x, const float* eps_hat, const int* t, const float* tables, int timesteps, float percentile,
+                          float* thres_out, int batch, int channels, long per_sample, void* stream) {
+    if (!x || !eps_hat || !t || !tables || !thres_out || batch < 1 || channels < 1 || per_sample < 1) VDX_FAIL(VDX_ERR_INVALID, "dynamic_threshold: bad argument");
+    if (!(percentile > 0.f && percentile <= 1.f) || per_sample % channels) VDX_FAIL(VDX_ERR_INVALID, "dynamic_threshold: percentile must be in (0, 1]");
+    VDX_HIP(vdx::launch_dyn_thres(x, eps_hat, t, tables, timesteps, percentile, thres_out, batch, channels, per_sample, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_p_sample_loop_dyn(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
+                          uint64_t* step_dev, const float* tables, int timesteps, int nsteps, const float* cond, uint64_t seed,
+                          int clip_denoised, float percentile, float* thres_buf, void* workspace, size_t workspace_bytes, int batch,
+                          int use_graph, void* stream) {
     if (!h || !params || !packed || !img || !eps_buf || !t_dev || !step_dev || !tables || !workspace) VDX_FAIL(VDX_ERR_INVALID, "p_sample_loop: null argument");
     if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "p_sample_loop: handle was created without a GPU");
     if (nsteps < 0 || nsteps > timesteps) VDX_FAIL(VDX_ERR_INVALID, "p_sample_loop: nsteps out of range");
+    const bool dyn = percentile > 0.f && clip_denoised;
+    if (dyn && (!thres_buf || percentile > 1.f)) VDX_FAIL(VDX_ERR_INVALID, "p_sample_loop: dynamic threshold needs thres_buf and a percentile in (0, 1]");
     const vdx::Model& m = h->model;
     const long per_sample = (long)m.cfg.channels * m.cfg.num_frames * m.cfg.image_size * m.cfg.image_size;
     if (per_sample % 4) VDX_FAIL(VDX_ERR_INVALID, "p_sample_loop: C*F*H*W must be a multiple of 4");
@@ -315,40 +358,65 @@ int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, fl
         // reference p_sample_loop never forwards cond (Q10); when a cond tensor is supplied it is used un-masked
         int rc = vdx::model_forward(&m, params, packed, img, t_dev, cond, nullptr, 0, eps_buf, workspace, workspace_bytes, batch, st);
         if (rc != VDX_OK) return rc;
+        hipError_t e = hipSuccess;
+        if (dyn) e = vdx::launch_dyn_thres(img, eps_buf, t_dev, tables, timesteps, percentile, thres_buf, batch, m.cfg.channels, per_sample, st);
         vdx::PSampleArgs a;
-        fill_psample(a, img, eps_buf, img, t_dev, tables, timesteps, nullptr, seed, 1, step_dev, nullptr, clip_denoised, m.cfg.channels, per_sample);
-        hipError_t e = vdx::launch_p_sample(a, batch, st);
+        fill_psample(a, img, eps_buf, img, t_dev, tables, timesteps, nullptr, seed, 1, step_dev, dyn ? thres_buf : nullptr, clip_denoised, m.cfg.channels, per_sample);
+        if (e == hipSuccess) e = vdx::launch_p_sample(a, batch, st);
         if (e == hipSuccess) e = vdx::launch_advance(t_dev, batch, reinterpret_cast<unsigned long long*>(step_dev), st);
         if (e != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__);
         return VDX_OK;
     };
-    if (!use_graph) {
-        for (int i = 0; i < nsteps; ++i) { int rc = step(); if (rc != VDX_OK) return rc; }
-        return VDX_OK;
-    }
     vdx_handle::GraphKey key;
     memset(&key, 0, sizeof(key));
     key.p[0] = params; key.p[1] = packed; key.p[2] = img; key.p[3] = eps_buf; key.p[4] = t_dev; key.p[5] = step_dev;
-    key.p[6] = tables; key.p[7] = cond; key.seed = seed; key.i[0] = timesteps; key.i[1] = clip_denoised | (h->model.act16 << 8); key.i[2] = batch;
-    key.p[8] = workspace; key.p[9] = stream; key.ws = workspace_bytes;
-    int done = 0;
-    if (!h->graph_exec || memcmp(&key, &h->graph_key, sizeof(key)) != 0) {
-        if (nsteps == 0) return VDX_OK;
-        int rc = step();                                    // eager first step (also sets kernel attributes before capture)
-        if (rc != VDX_OK) return rc;
-        done = 1;
-        if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
-        if (h->graph) { (void)hipGraphDestroy(h->graph); h->graph = nullptr; }
-        VDX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-        rc = step();
-        hipError_t ce = hipStreamEndCapture(st, &h->graph);
-        if (rc != VDX_OK) return rc;
-        if (ce != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(ce), __FILE__, __LINE__);
-        VDX_HIP(hipGraphInstantiate(&h->graph_exec, h->graph, nullptr, nullptr, 0));
-        h->graph_key = key;
-    }
-    for (int i = done; i < nsteps; ++i) VDX_HIP(hipGraphLaunch(h->graph_exec, st));
+    key.p[6] = tables; key.p[7] = cond; key.p[8] = workspace; key.p[9] = stream; key.p[10] = dyn ? thres_buf : nullptr;
+    key.seed = seed; key.i[0] = timesteps; key.i[1] = clip_denoised | (h->model.act16 << 8); key.i[2] = batch;
+    key.ws = workspace_bytes; key.f = dyn ? percentile : 0.f;
+    return run_steps(h, 0, key, nsteps, use_graph, st, step);
+}
+
+int vdx_p_sample_loop(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
+                      uint64_t* step_dev, const float* tables, int timesteps, int nsteps, const float* cond, uint64_t seed,
+                      int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream) {
+    return vdx_p_sample_loop_dyn(h, params, packed, img, eps_buf, t_dev, step_dev, tables, timesteps, nsteps, cond, seed, clip_denoised,
+                                 0.f, nullptr, workspace, workspace_bytes, batch, use_graph, stream);
+}
+
+int vdx_ddim_step(const float* x, const float* eps_hat, float* out, const float* alphas_cumprod, const int* seq,
+                  const uint64_t* step_dev, const float* thres, int clip_denoised, int batch, int channels, long per_sample, void* stream) {
+    if (!x || !eps_hat || !out || !alphas_cumprod || !seq || batch < 1 || channels < 1 || per_sample < 1 || per_sample % channels)
+        VDX_FAIL(VDX_ERR_INVALID, "ddim_step: bad argument");
+    VDX_HIP(vdx::launch_ddim_step(x, eps_hat, out, alphas_cumprod, seq, reinterpret_cast<const unsigned long long*>(step_dev), thres,
+                                  clip_denoised, batch, channels, per_sample, (hipStream_t)stream));
     return VDX_OK;
+}
+
+int vdx_ddim_sample_loop(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
+                         uint64_t* step_dev, const float* alphas_cumprod, const int* seq, int seq_len, int nsteps, const float* cond,
+                         int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream) {
+    if (!h || !params || !packed || !img || !eps_buf || !t_dev || !step_dev || !alphas_cumprod || !seq || !workspace) VDX_FAIL(VDX_ERR_INVALID, "ddim_sample_loop: null argument");
+    if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "ddim_sample_loop: handle was created without a GPU");
+    if (seq_len < 1 || nsteps < 0 || nsteps > seq_len) VDX_FAIL(VDX_ERR_INVALID, "ddim_sample_loop: nsteps out of range");
+    const vdx::Model& m = h->model;
+    const long per_sample = (long)m.cfg.channels * m.cfg.num_frames * m.cfg.image_size * m.cfg.image_size;
+    if (m.out_dim != m.cfg.channels) VDX_FAIL(VDX_ERR_INVALID, "ddim_sample_loop: out_dim must equal channels");
+    hipStream_t st = (hipStream_t)stream;
+    auto step = [&]() -> int {
+        int rc = vdx::model_forward(&m, params, packed, img, t_dev, cond, nullptr, 0, eps_buf, workspace, workspace_bytes, batch, st);
+        if (rc != VDX_OK) return rc;
+        hipError_t e = vdx::launch_ddim_step(img, eps_buf, img, alphas_cumprod, seq, reinterpret_cast<const unsigned long long*>(step_dev), nullptr,
+                                             clip_denoised, batch, m.cfg.channels, per_sample, st);
+        if (e == hipSuccess) e = vdx::launch_ddim_advance(t_dev, batch, seq, reinterpret_cast<unsigned long long*>(step_dev), st);
+        if (e != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__);
+        return VDX_OK;
+    };
+    vdx_handle::GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.p[0] = params; key.p[1] = packed; key.p[2] = img; key.p[3] = eps_buf; key.p[4] = t_dev; key.p[5] = step_dev;
+    key.p[6] = alphas_cumprod; key.p[7] = cond; key.p[8] = workspace; key.p[9] = stream; key.p[10] = seq;
+    key.i[0] = seq_len; key.i[1] = clip_denoised | (h->model.act16 << 8); key.i[2] = batch; key.ws = workspace_bytes;
+    return run_steps(h, 1, key, nsteps, use_graph, st, step);
 }
 
 int vdx_pack_conv_weights_t(int mode, const float* kernel, void* packed, int taps, int cin, int cout, void* stream) {

@@ -118,6 +118,11 @@ hipError_t launch_q_sample(const float* x0, const int* t, const float* noise, fl
                            int B, long per_sample, float pre_scale, float pre_shift, hipStream_t st);
 hipError_t launch_p_sample(const PSampleArgs& a, int B, hipStream_t st);
 hipError_t launch_advance(int* t, int B, unsigned long long* dev_offset, hipStream_t st);
+hipError_t launch_ddim_step(const float* x, const float* eps, float* out, const float* ac, const int* seq, const unsigned long long* step_dev,
+                            const float* thres, int clip, int B, int C, long per_sample, hipStream_t st);
+hipError_t launch_ddim_advance(int* t, int B, const int* seq, unsigned long long* step_dev, hipStream_t st);
+hipError_t launch_dyn_thres(const float* x, const float* eps, const int* t, const float* tables, int T, float q, float* out, int B, int C,
+                            long per_sample, hipStream_t st);
 hipError_t launch_loss(const float* eps_hat, const float* noise, double* acc, int B, int Cc, long fhw, int l2, hipStream_t st);
 hipError_t launch_affine(const float* x, float* y, long n, float a, float b, hipStream_t st);
 

@@ -24,6 +24,18 @@ vdx_p_sample_step = L._sig('vdx_p_sample_step', C.c_int, [_vp] * 5 + [C.c_int, _
 vdx_loss_sum = L._sig('vdx_loss_sum', C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_long, C.c_int, _vp])
 vdx_affine = L._sig('vdx_affine', C.c_int, [_vp, _vp, C.c_long, C.c_float, C.c_float, _vp])
 vdx_p_sample_loop = L._sig('vdx_p_sample_loop', C.c_int, [_vp] * 8 + [C.c_int, C.c_int, _vp, _u64, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int, _vp])
+vdx_p_sample_loop_dyn = L._sig('vdx_p_sample_loop_dyn', C.c_int, [_vp] * 8 + [C.c_int, C.c_int, _vp, _u64, C.c_int, C.c_float, _vp, _vp, C.c_size_t,
+                                                                 C.c_int, C.c_int, _vp])
+vdx_dynamic_threshold = L._sig('vdx_dynamic_threshold', C.c_int, [_vp] * 4 + [C.c_int, C.c_float, _vp, C.c_int, C.c_int, C.c_long, _vp])
+vdx_ddim_step = L._sig('vdx_ddim_step', C.c_int, [_vp] * 7 + [C.c_int, C.c_int, C.c_int, C.c_long, _vp])
+vdx_ddim_sample_loop = L._sig('vdx_ddim_sample_loop', C.c_int, [_vp] * 9 + [C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int, _vp])
+
+
+def ddim_time_sequence(timesteps: int, steps: int) -> np.ndarray:
+    """The S + 1 times of an S-step DDIM chain over a T-step schedule: T-1 = t_0 > t_1 > ... > t_{S-1} >= 0, then -1 (= the data).
+    Evenly spaced as linspace(-1, T-1, S+1), the usual choice (denoising-diffusion-pytorch); the reference has no DDIM."""
+    assert 1 <= steps <= timesteps
+    return np.ascontiguousarray(np.linspace(-1, timesteps - 1, steps + 1).astype(np.int32)[::-1])
 
 TABLE_NAMES = (
     'alphas_cumprod', 'sqrt_alphas_cumprod', 'sqrt_one_minus_alphas_cumprod', 'log_one_minus_alphas_cumprod',
@@ -137,11 +149,13 @@ class GaussianDiffusion:
         return x.numel() // x.shape[0]
 
     def _dynamic_threshold(self, x, t, eps_hat):
-        """Imagen dynamic thresholding (reference :205-217); the quantile is a torch op (optional, non-default path)."""
-        pred = eps_hat.permute(0, 4, 1, 2, 3)
-        x_recon = self.predict_start_from_noise(x, t, pred)
-        s = torch.quantile(x_recon.abs().reshape(x.shape[0], -1), self.dynamic_thres_percentile, dim=-1)
-        return s.clamp_min(1.0).contiguous()
+        """Imagen dynamic thresholding (reference :205-217): s = max(quantile(|x0_hat| per sample, percentile), 1), exact radix
+        select on the device (vdx_dynamic_threshold)."""
+        s = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        L.check(vdx_dynamic_threshold(L.ptr(x), L.ptr(eps_hat), L.ptr(t), L.ptr(self._ptab), self.num_timesteps,
+                                      float(self.dynamic_thres_percentile), L.ptr(s), x.shape[0], self.channels, self._per_sample(x),
+                                      L.stream_ptr()))
+        return s
 
     # -- reverse process ---------------------------------------------------------------------------
     def p_mean_variance(self, x, t, clip_denoised: bool, cond=None, cond_scale: float = 1.0):
@@ -200,7 +214,7 @@ class GaussianDiffusion:
         with torch.cuda.stream(st):
             img = self.randn(shape, seed, 0) if x_T is None else self._dev(x_T).clone()
             guided = cond is not None and unet.has_cond and cond_scale != 1
-            if self.use_dynamic_thres or guided:
+            if guided:
                 for k, i in enumerate(reversed(range(T))):
                     t = torch.full((B,), i, dtype=torch.int32, device=self.device)
                     eps_hat = unet.forward_with_cond_scale(img, t, cond=cond, cond_scale=cond_scale)
@@ -215,21 +229,69 @@ class GaussianDiffusion:
                 eps = torch.empty(B, self.num_frames, self.image_size, self.image_size, unet.out_dim, dtype=torch.float32, device=self.device)
                 t_dev = torch.full((B,), T - 1, dtype=torch.int32, device=self.device)
                 step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
-                L.check(vdx_p_sample_loop(h.ptr, L.ptr(unet.flat_params), L.ptr(unet.packed()), L.ptr(img), L.ptr(eps), L.ptr(t_dev),
-                                          L.ptr(step_dev), L.ptr(self._ptab), T, T, L.ptr(condd), seed, 1, L.ptr(ws), ws.numel(), B,
-                                          int(use_graph), L.stream_ptr()))
+                thres = torch.empty(B, dtype=torch.float32, device=self.device) if self.use_dynamic_thres else None
+                L.check(vdx_p_sample_loop_dyn(h.ptr, L.ptr(unet.flat_params), L.ptr(unet.packed()), L.ptr(img), L.ptr(eps), L.ptr(t_dev),
+                                              L.ptr(step_dev), L.ptr(self._ptab), T, T, L.ptr(condd), seed, 1,
+                                              float(self.dynamic_thres_percentile) if self.use_dynamic_thres else 0.0, L.ptr(thres),
+                                              L.ptr(ws), ws.numel(), B, int(use_graph), L.stream_ptr()))
             out = torch.empty_like(img)
             L.check(vdx_affine(L.ptr(img), L.ptr(out), img.numel(), 0.5, 0.5, L.stream_ptr()))     # unnormalize_img
         return out
 
-    def sample(self, key, cond=None, cond_scale: float = 1.0, batch_size: int = 16, **kw):
-        """reference :323-357."""
+    def ddim_sample_loop(self, shape, key, steps: int = 100, cond=None, cond_scale: float = 1.0, *, use_graph: bool = True, x_T=None):
+        """DDIM sampling with eta = 0 in `steps` network evaluations (EXTENSION, BASELINE.json configs[3]; the reference has ancestral
+        sampling only).  x_T = Philox(key, draw 0), deterministic afterwards.  Returns unnormalize_img(x_0) in [0, 1]."""
+        B = int(shape[0])
+        shape = (B, self.channels, self.num_frames, self.image_size, self.image_size)
+        unet = self.denoise_fn
+        seq_host = ddim_time_sequence(self.num_timesteps, steps)
+        if self._sample_stream is None:
+            self._sample_stream = torch.cuda.Stream(device=self.device)
+        cur, st = torch.cuda.current_stream(self.device), self._sample_stream
+        st.wait_stream(cur)
+        keep_storage = unet.act_bf16
+        unet.act_bf16 = bool(self.sample_act_bf16 and unet.mode == 'bf16')
+        try:
+            with torch.cuda.stream(st):
+                img = self.randn(shape, int(key) & 0xFFFFFFFFFFFFFFFF, 0) if x_T is None else self._dev(x_T).clone()
+                seq = torch.from_numpy(seq_host).to(self.device)
+                guided = cond is not None and unet.has_cond and cond_scale != 1
+                if guided:
+                    step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+                    for k in range(steps):
+                        t = torch.full((B,), int(seq_host[k]), dtype=torch.int32, device=self.device)
+                        eps_hat = unet.forward_with_cond_scale(img, t, cond=cond, cond_scale=cond_scale)
+                        step_dev.fill_(k)
+                        L.check(vdx_ddim_step(L.ptr(img), L.ptr(eps_hat), L.ptr(img), L.ptr(self.alphas_cumprod), L.ptr(seq), L.ptr(step_dev), 0, 1,
+                                              B, self.channels, self._per_sample(img), L.stream_ptr()))
+                else:
+                    condd = None if (cond is None or not unet.has_cond) else self._dev(cond)
+                    h = unet.handle(self.num_frames, self.image_size)
+                    unet.apply_activation_storage(h)
+                    ws = unet.workspace(B, self.num_frames, self.image_size)
+                    eps = torch.empty(B, self.num_frames, self.image_size, self.image_size, unet.out_dim, dtype=torch.float32, device=self.device)
+                    t_dev = torch.full((B,), int(seq_host[0]), dtype=torch.int32, device=self.device)
+                    step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+                    L.check(vdx_ddim_sample_loop(h.ptr, L.ptr(unet.flat_params), L.ptr(unet.packed()), L.ptr(img), L.ptr(eps), L.ptr(t_dev),
+                                                 L.ptr(step_dev), L.ptr(self.alphas_cumprod), L.ptr(seq), steps, steps, L.ptr(condd), 1,
+                                                 L.ptr(ws), ws.numel(), B, int(use_graph), L.stream_ptr()))
+                out = torch.empty_like(img)
+                L.check(vdx_affine(L.ptr(img), L.ptr(out), img.numel(), 0.5, 0.5, L.stream_ptr()))     # unnormalize_img
+        finally:
+            unet.act_bf16 = keep_storage
+        cur.wait_stream(st)
+        return out
+
+    def sample(self, key, cond=None, cond_scale: float = 1.0, batch_size: int = 16, *, ddim_steps: Optional[int] = None, **kw):
+        """reference :323-357.  ddim_steps (extension): sample with an S-step DDIM chain instead of the T-step ancestral one."""
         if is_list_str(cond):
             raise NotImplementedError('text -> BERT embedding needs the external video_diffusion_pytorch.text (network fetch); '
                                       'pass a ready [B, 768] tensor instead')
         if cond is not None:
             batch_size = cond.shape[0]
         shape = (batch_size, self.channels, self.num_frames, self.image_size, self.image_size)
+        if ddim_steps:
+            return self.ddim_sample_loop(shape, key, steps=int(ddim_steps), cond=cond, cond_scale=cond_scale, **kw)
         return self.p_sample_loop(shape, key, cond=cond, cond_scale=cond_scale, **kw)
 
     def interpolate(self, x1, x2, t: Optional[int] = None, lam: float = 0.5, key: int = 0):
