@@ -167,12 +167,11 @@ def test_ddim_step_elementwise_and_sequence():
     x = torch.randn(B, C, 4, 8, 8, generator=g)
     eps = torch.randn(B, 4, 8, 8, C, generator=g)
     ac = torch.from_numpy(make_tables(1000)['alphas_cumprod'])
-    seqd = torch.from_numpy(seq).to(dev)
+    seqd, xd, epsd, acd = torch.from_numpy(seq).to(dev), x.to(dev), eps.to(dev), ac.to(dev)
     for k in (0, 57, 99):                                     # first, middle, last (t_next = -1: the data itself)
         step = torch.full((1,), k, dtype=torch.int64, device=dev)
         out = torch.empty(B, C, 4, 8, 8, device=dev)
-        L.check(vdx_ddim_step(L.ptr(x.to(dev)), L.ptr(eps.to(dev)), L.ptr(out), L.ptr(ac.to(dev)), L.ptr(seqd), L.ptr(step), 0, 1, B, C, per,
-                              L.stream_ptr()))
+        L.check(vdx_ddim_step(L.ptr(xd), L.ptr(epsd), L.ptr(out), L.ptr(acd), L.ptr(seqd), L.ptr(step), 0, 1, B, C, per, L.stream_ptr()))
         t, tn = int(seq[k]), int(seq[k + 1])
         a_t, a_n = ac[t].double(), (ac[tn].double() if tn >= 0 else torch.tensor(1.0, dtype=torch.float64))
         e = eps.permute(0, 4, 1, 2, 3).double()
@@ -202,7 +201,7 @@ def test_ddim_sample_loop_matches_oracle(use_graph):
     err = (out.cpu().double() - exp).abs().max().item()
     assert err < 5e-4, err
     again = gd.sample(11, batch_size=2, ddim_steps=S, use_graph=use_graph)       # deterministic given the seed; reuses the cached graph
-    assert torch.equal(again, out)
+    assert torch.allclose(again, out, atol=1e-5)             # (f64 atomics of the GroupNorm statistics: last-bit jitter only)
 
 
 def test_dynamic_threshold_quantile_and_graph_loop():
@@ -224,11 +223,11 @@ def test_dynamic_threshold_quantile_and_graph_loop():
     x = 2.5 * torch.randn(B, 3, 5, 8, 8, generator=g)
     eps = torch.randn(B, 5, 8, 8, 3, generator=g)
     t = torch.tensor([0, 5, 11], dtype=torch.int32)
+    xd, epsd, td = x.to(dev), eps.to(dev), t.to(dev)
     for q in (0.9, 0.5, 1.0, 0.123):
         s = torch.empty(B, device=dev)
-        L.check(vdx_dynamic_threshold(L.ptr(x.to(dev)), L.ptr(eps.to(dev)), L.ptr(t.to(dev)), L.ptr(gd._ptab), T, q, L.ptr(s), B, 3, 3 * 5 * 64,
-                                      L.stream_ptr()))
-        xr = gd.predict_start_from_noise(x.to(dev), t.to(dev), eps.to(dev).permute(0, 4, 1, 2, 3)).cpu()
+        L.check(vdx_dynamic_threshold(L.ptr(xd), L.ptr(epsd), L.ptr(td), L.ptr(gd._ptab), T, q, L.ptr(s), B, 3, 3 * 5 * 64, L.stream_ptr()))
+        xr = gd.predict_start_from_noise(xd, td, epsd.permute(0, 4, 1, 2, 3)).cpu()
         ref = torch.quantile(xr.abs().reshape(B, -1), q, dim=-1).clamp_min(1.0)
         assert torch.allclose(s.cpu(), ref, rtol=1e-6, atol=1e-6), (q, s.cpu(), ref)
     shape = (2, 3, 5, 8, 8)

@@ -621,7 +621,7 @@ static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
     const long subtiles = (a.nseq + 3) / 4;
     // sub-tiles per workgroup: the per-head weight fragments (12 KB per wave) are loaded once per workgroup, so fatter workgroups
     // amortise them as long as ~1024 workgroups remain to fill the chip
-    static const int nsub_cap = getenv("VDX_ATTN_NSUB") ? atoi(getenv("VDX_ATTN_NSUB")) : 32;
+    const int nsub_cap = 32;
     const int nsub = (int)std::min<long>(nsub_cap, std::max<long>(1, subtiles / 1024));
     const long blocks = (subtiles + nsub - 1) / nsub;
     hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, st, a, nsub);
@@ -828,8 +828,8 @@ static hipError_t launch_attn_l(const AttnArgs& a, hipStream_t st) {
 
 template <int MODE>
 static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
-    static const bool use_reg = getenv("VDX_ATTN_LDS") == nullptr;        // debugging switch: force the LDS-staged kernel
-    static const bool use_h8 = getenv("VDX_ATTN_NOH8") == nullptr;        // debugging switch: skip the one-wave-per-head kernel
+    const bool use_reg = true;        // debugging switch: force the LDS-staged kernel
+    const bool use_h8 = true;        // debugging switch: skip the one-wave-per-head kernel
     const bool h8_ok = a.L <= 16 && a.heads == 8 && a.inner % 4 == 0 && a.nseq % 4 == 0 && a.nseq < (1L << 31) &&
                        3 * a.inner_stride + 15 * a.tok_stride + a.C < (1L << 31);
     if (h8_ok && use_reg && use_h8) {

@@ -285,49 +285,25 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
         }
         int dy = 0, dx = 0;
         for (int tap = 0; tap < ntaps; ++tap) {
-#if defined(VDX_DIAG_NOWLOAD)                             // timing diagnostics (tools/conv_diag.sh): compile-time only, results are WRONG
-            if (cc == 0 && tap == 0) wstore(buf);
-#else
             wstore(buf);
-#endif
-#if defined(VDX_DIAG_NOBAR)
-            if (tap == 0) __syncthreads();
-#else
             __syncthreads();
-#endif
             int ndy = dy, ndx = dx + 1, ncc = cc;
             if (ndx == KW) { ndx = 0; ndy = dy + 1; }
             if (ndy == KH) { ndy = 0; ncc = cc + 1; }
-#if !defined(VDX_DIAG_NOWLOAD)
             if (ncc < nchunks) wload(ndy, ndx, ncc);      // prefetch the next weight tile while this one is consumed
-#endif
             const int tapoff = (dy * IW + dx) * RS;
             const char* wt = Ws + buf * (BC * RS) + (wc * 64 + lp) * RS + q * 16;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 uint4 bf[TN], af[TM];
-#if defined(VDX_DIAG_NOFRAG)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) bf[tn] = make_uint4(lane, tapoff, ch, tn);
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) af[tm] = make_uint4(lane, tapoff, ch, tm);
-#else
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(As + pixoff[tn] + tapoff + ch * CHUNK_BYTES);
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm) af[tm] = *reinterpret_cast<const uint4*>(wt + tm * 16 * RS + ch * CHUNK_BYTES);
-#endif
-#if defined(VDX_DIAG_NOMFMA)
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) asm volatile("" :: "v"(af[tm].x), "v"(af[tm].y), "v"(af[tm].z), "v"(af[tm].w));
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn) asm volatile("" :: "v"(bf[tn].x), "v"(bf[tn].y), "v"(bf[tn].z), "v"(bf[tn].w));
-#else
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
-#endif
             }
             dy = ndy; dx = ndx;
             buf ^= 1;
@@ -576,7 +552,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
         const char* At = Al + buf * (C64_HALO * 128);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap == 5 && more) stage_store(buf ^ 1);
+            if (tap == 5 && more) stage_store(buf ^ 1);       // (loading two tiles ahead instead was measured slower: r02)
             const int dy = tap / 3, dx = tap % 3;
             int boff[2];
 #pragma unroll
@@ -973,8 +949,8 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
     a.x0_bytes = (unsigned)b0; a.x1_bytes = (unsigned)b1; a.w_bytes = (unsigned)bw;
     if (conv3x3_ws_eligible(mode, a)) return launch_conv3x3_ws(a, st);       // wide levels: persistent weight-streaming kernel
-    {   // persistent specialisation for the level-0 shape (see conv64p_kernel); VDX_CONV64P=0 disables it
-        static const int use64p = getenv("VDX_CONV64P") ? atoi(getenv("VDX_CONV64P")) : 1;
+    {   // persistent specialisation for the level-0 shape (see conv64p_kernel)
+        const int use64p = 1;
         const long tiles = (long)a.NF * (a.H / 16) * (a.W / 16);
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.C0 == 64 && a.C1 == 0 && a.Cout == 64 &&
             a.wrows == 64 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
@@ -989,7 +965,6 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     // variant: 64-channel tiles take 256 pixels per workgroup (stride 1) so every wave owns a 64x64 tile
     const int BC = a.Cout <= 64 ? 64 : 128;
     // 8-wave workgroups (each wave 32 pixels x 64 channels of the same workgroup tile): 4 waves per SIMD instead of 2;
-    // VDX_CONV_NW8=0 selects the 4-wave form (64 x 64 per wave) for comparison
     const int TN = (BC == 64 && a.stride == 2) ? 2 : 4;
     const int BM = 16 * TN * (4 / (BC / 64));
     choose_patch(BM, a.NF, a.F, a.Ho, a.Wo, a.stride, K, a.PH, a.PW, a.NP);

@@ -151,7 +151,7 @@ hipError_t launch_resblock_tail(TailArgs a, hipStream_t st) {
         // every workgroup starts with the statistics -> coefficient chain (a few dependent L2 round trips): give it
         // ~8 pixel passes of work when the launch has enough workgroups to fill the chip anyway
         // (~8 passes per workgroup, at least 2048 workgroups in the launch: 8192 at B = 32, 16384 at B = 64 measured best)
-        static const int tail_wgs = getenv("VDX_TAIL_WGS") ? atoi(getenv("VDX_TAIL_WGS")) : 0;
+        const int tail_wgs = 0;
         const long need = (a.pix_per_sample + ppb - 1) / ppb;
         const long total = tail_wgs > 0 ? tail_wgs : std::max<long>(2048, need * a.batch / 8);
         const int gx = (int)std::min<long>(need, std::max<long>(1, std::min<long>(2048, total / std::max(1, a.batch))));
@@ -169,7 +169,7 @@ hipError_t launch_resblock_tail(TailArgs a, hipStream_t st) {
     a.lpp = lpp;
     const int vpl = (quads + lpp - 1) / lpp;
     const int ppb = 256 / lpp;
-    static const int tail_wgs32 = getenv("VDX_TAIL_WGS") ? atoi(getenv("VDX_TAIL_WGS")) : 0;
+    const int tail_wgs32 = 0;
     const long need32 = (a.pix_per_sample + ppb - 1) / ppb;
     const long total32 = tail_wgs32 > 0 ? tail_wgs32 : std::max<long>(2048, need32 * a.batch / 8);
     int gx = (int)std::min<long>(need32, std::max<long>(1, std::min<long>(2048, total32 / std::max(1, a.batch))));

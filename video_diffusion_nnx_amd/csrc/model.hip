@@ -401,8 +401,8 @@ static hipError_t run_attn(const Fwd& f, const AttnP& ap, const float* x, float*
     if (temporal) { a.L = (int)Fr; a.nseq = f.B * hw; a.inner = hw; a.inner_stride = ap.C; a.outer_stride = Fr * hw * ap.C; a.tok_stride = hw * ap.C; }
     else { a.L = (int)hw; a.nseq = f.B * Fr; a.inner = 1; a.inner_stride = 0; a.outer_stride = hw * ap.C; a.tok_stride = ap.C; }
     a.io_bf16 = f.a16;
-    // wide levels in bf16 mode: per-head kernel (weights resident in LDS) + the out-projection as a 1x1 conv; VDX_ATTN_HEADS=0 disables
-    static const int use_heads = getenv("VDX_ATTN_HEADS") ? atoi(getenv("VDX_ATTN_HEADS")) : 1;
+    // wide levels in bf16 mode: per-head kernel (weights resident in LDS) + the out-projection as a 1x1 conv
+    const int use_heads = 1;
     if (use_heads && m->mode == MODE_BF16 && temporal && a.L <= 16 && a.heads == 8 && ap.C >= 256 && ap.C % 128 == 0 &&
         (size_t)96 * (ap.C * 2 + 32) <= 160 * 1024 && (size_t)Fr * S * S * a.heads * 64 <= m->sla_ws_bytes_per_sample) {
         a.oscratch = f.sla_ws;
@@ -427,8 +427,8 @@ static hipError_t run_sla(const Fwd& f, const SlaP& sp, const float* x, float* y
     a.x = x; a.y = y; a.wq = f.pk + sp.pk[0]; a.wk = f.pk + sp.pk[1]; a.wv = f.pk + sp.pk[2]; a.wo = f.pk + sp.pk_o;
     a.workspace = f.sla_ws; a.C = sp.C; a.heads = m->cfg.attn_heads; a.NF = f.B * m->cfg.num_frames; a.N = S * S;
     a.io_bf16 = f.a16;
-    // wide levels in bf16 mode: per-head kernel (weights resident in LDS) + to_out as a 1x1 conv; VDX_SLA_HEADS=0 disables
-    static const int use_heads = getenv("VDX_SLA_HEADS") ? atoi(getenv("VDX_SLA_HEADS")) : 1;
+    // wide levels in bf16 mode: per-head kernel (weights resident in LDS) + to_out as a 1x1 conv
+    const int use_heads = 1;
     if (use_heads && m->mode == MODE_BF16 && a.heads == 8 && sp.C >= 256 && sp.C % 128 == 0 && a.N % 16 == 0 &&
         (size_t)96 * (sp.C * 2 + 32) <= 160 * 1024 && (size_t)m->cfg.num_frames * a.N * a.heads * 64 <= m->sla_ws_bytes_per_sample) {
         hipError_t e = launch_sla_heads(a, f.sla_ws, f.st);

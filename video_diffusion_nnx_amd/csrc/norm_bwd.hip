@@ -262,7 +262,7 @@ hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st) {
     // few, fat workgroups: every workgroup ends in 2..4 atomics per channel onto the same [B][C] rows (contention-bound beyond ~64)
     // the reduce pass is a latency-bound stream (one pixel group in flight per lane group): enough workgroups to give every
     // SIMD several waves, few enough that the per-workgroup table build and the 2C..4C atomics of the flush stay small
-    static const int red_wgs = getenv("VDX_NORMBWD_WGS") ? atoi(getenv("VDX_NORMBWD_WGS")) : 192;
+    const int red_wgs = 192;
     const int gx = (int)std::max<long>(1, std::min<long>((a.pix_per_sample + ppb - 1) / ppb, std::max(1, red_wgs / std::max(1, a.batch))));
     if (!a.r_clean) {
         hipError_t e = hipMemsetAsync(a.R, 0, (size_t)a.batch * a.C * 2 * 4, st);

@@ -922,14 +922,14 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
     // traffic (8 x 4.4 KB per chunk, written here and re-read by the combine) per doubling
     {
         const int tiles = (a.N + 63) / 64;
-        static const long min_wgs = getenv("VDX_SLA_MINWG") ? atol(getenv("VDX_SLA_MINWG")) : 1024;
+        const long min_wgs = 1024;
         while (a.nsub * 2 <= tiles && (long)a.NF * ((tiles + 2 * a.nsub - 1) / (2 * a.nsub)) >= min_wgs) a.nsub *= 2;
         a.nchunk = (tiles + a.nsub - 1) / a.nsub;
     }
     const size_t part_bytes = (((size_t)a.NF * a.nchunk * a.heads * SLA_PART * 4) + 255) / 256 * 256;
     a.part = reinterpret_cast<float*>(a.workspace);
     a.ctxT = reinterpret_cast<char*>(a.workspace) + part_bytes;
-    static const bool generic_only = getenv("VDX_SLA_GENERIC") != nullptr;
+    const bool generic_only = false;
     const int nkt = a.CPad / M::KT;
     if (a.heads == 8 && a.C % 64 == 0 && !generic_only) {     // one wave per head; x tile double-buffered in LDS
         if constexpr (MODE == MODE_BF16) {

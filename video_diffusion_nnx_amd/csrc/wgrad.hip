@@ -659,7 +659,7 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
     } else {
         a.sa = 1; a.sb = 2; a.ext = 3; a.halo = 1; a.Hm = a.H; a.Wm = a.W; a.Hy = 2 * a.H; a.Wy = 2 * a.W; a.PH = 4; a.PW = 8;
     }
-    static const int wide_patch = getenv("VDX_WGRAD_PW16") ? atoi(getenv("VDX_WGRAD_PW16")) : 1;
+    const int wide_patch = 1;
     if (a.bf16_mma && a.kind == 0 && a.stride == 1 && a.kh == 3 && wide_patch && a.W >= 16) { a.PH = 8; a.PW = 16; }   // bf16 form: 128 positions per patch
     const int NT = a.taps <= 9 ? (a.taps == 1 ? 1 : 9) : 8;
     const int tap_groups = (a.taps + NT - 1) / NT;
@@ -669,10 +669,10 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
     const size_t lds = ((size_t)IH * IW + (size_t)a.PH * a.sb * a.PW * a.sb) * WG_LD * 4 + 3 * 64 * 4 + 32 * 4;
     const long patches = (long)a.NF * ((a.Hm + a.PH - 1) / a.PH) * ((a.Wm + a.PW - 1) / a.PW);
     const long tiles = (long)ci_tiles * a.co_tiles * tap_groups;
-    static const long target_wgs = getenv("VDX_WGRAD_WGS") ? atol(getenv("VDX_WGRAD_WGS")) : 1024;
+    const long target_wgs = 1024;
     // multi-tap tiles: the epilogue is 64 x 64 x NT atomic adds per workgroup and the chip sustains about one 256-byte atomic wave
     // instruction per 50 ns per CU, so 1024 workgroups spend ~115 us in the epilogue alone; 256 (one per CU) measured best
-    static const long target_wgs9 = getenv("VDX_WGRAD_WGS9") ? atol(getenv("VDX_WGRAD_WGS9")) : 256;
+    const long target_wgs9 = 256;
     long chunks = std::max<long>(1, std::min<long>(patches, (a.taps > 1 ? target_wgs9 : target_wgs) / std::max<long>(1, tiles)));
     dim3 grid((unsigned)chunks, ci_tiles, a.co_tiles * tap_groups);
     if (a.bf16_mma && (a.PW == 8 || a.PW == 16)) {
@@ -689,9 +689,9 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
         }
         if (a.x0_bf16 && a.C1) return hipErrorInvalidValue;      // the bf16 x0 form has no concat operand
         // projections: the split-K GEMM form (wide output tiles when Cout allows: x is staged Cout / 256 times instead of Cout / 64)
-        static const int use_1x1 = getenv("VDX_WGRAD_1X1") ? atoi(getenv("VDX_WGRAD_1X1")) : 2;   // 0: patch kernel, 1: GEMM form for wide outputs only, 2: always
+        const int use_1x1 = 2;   // 0: patch kernel, 1: GEMM form for wide outputs only, 2: always
         if (use_1x1 && NT == 1 && a.kind == 0 && a.stride == 1 && !a.pro && (a.Cout % 256 == 0 || use_1x1 == 2)) {
-            static const long wgs4 = getenv("VDX_WGRAD_WGS4") ? atol(getenv("VDX_WGRAD_WGS4")) : 512;
+            const long wgs4 = 512;
             if (a.Cout % 256 == 0) {
                 if (a.x0_bf16) return a.dy_bf16 ? launch_wgrad1x1_t<true, true, 4>(a, wgs4, st) : launch_wgrad1x1_t<true, false, 4>(a, wgs4, st);
                 return a.dy_bf16 ? launch_wgrad1x1_t<false, true, 4>(a, wgs4, st) : launch_wgrad1x1_t<false, false, 4>(a, wgs4, st);
@@ -699,7 +699,7 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
             if (a.x0_bf16) return a.dy_bf16 ? launch_wgrad1x1_t<true, true, 1>(a, target_wgs, st) : launch_wgrad1x1_t<true, false, 1>(a, target_wgs, st);
             return a.dy_bf16 ? launch_wgrad1x1_t<false, true, 1>(a, target_wgs, st) : launch_wgrad1x1_t<false, false, 1>(a, target_wgs, st);
         }
-        static const bool pf1 = getenv("VDX_WGRAD_PF1") ? atoi(getenv("VDX_WGRAD_PF1")) != 0 : false;
+        const bool pf1 = false;
 #define VDX_WG16_IO(NT_, NG_, PF_) do { if (a.x0_bf16) { if (a.dy_bf16) VDX_WG16(NT_, NG_, PF_, true, true); else VDX_WG16(NT_, NG_, PF_, true, false); } \
                                         else { if (a.dy_bf16) VDX_WG16(NT_, NG_, PF_, false, true); else VDX_WG16(NT_, NG_, PF_, false, false); } } while (0)
         if (NT == 1) { if (pf1) VDX_WG16_IO(1, 1, true); else VDX_WG16_IO(1, 1, false); }
