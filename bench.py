@@ -128,7 +128,8 @@ def time_conv_kernels(unet, frames, size, batch, mode, act='f32', reps=5):
         if mode == 'bf16' and act == 'bf16' and kind in ('c3', 'c3p') and cout % 128 == 0 and cin % 64 == 0 and (s % 16 == 0 or s == 8):
             tiles = batch * frames * (s // 16) ** 2 if s % 16 == 0 else batch * frames // 4
             if tiles * (cout // 128) >= 128 and cout // 128 in (1, 2, 4, 8):               # conv3x3_ws_eligible (conv_ws.hip)
-XX
+                geo = 8 if s == 8 else (16 if s == 16 else 0)                            # conv_ws.hip ws_geo(): whole frames / 16 x 16 tiles
+                sym = f'vdx::conv3x3_ws_kernel<{geo}, {"true" if kind == "c3p" else "false"}>'
         launches = 4 if kind == 'up' else 1                                              # the 4 phases are one launch (grid.z)
         d = per_symbol.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
         d['ms'] += ms; d['flops'] += conv_flops(layer, frames, batch); d['bytes'] += conv_bytes(layer, frames, batch, mode, act); d['launches'] += 1
