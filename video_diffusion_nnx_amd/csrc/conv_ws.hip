@@ -48,14 +48,22 @@ __device__ __forceinline__ unsigned lds_addr(const char* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-// position-swizzled byte offset of 16-byte chunk (4 ks + q) of LDS row `row`, for ks = 0; ks = 1 is this ^ 64
-__device__ __forceinline__ int frag_off(int row, int q) { return row * 128 + (((q ^ (row & 3)) | (row & 4)) << 4); }
+// byte offset of 16-byte chunk (4 ks + q) of LDS row `row` whose swizzle key is `key` (chunk k sits at position k ^ (key & 7)), for
+// ks = 0; ks = 1 is this ^ 64
+__device__ __forceinline__ int frag_off(int row, int key, int q) { return row * 128 + (((q ^ (key & 3)) | (key & 4)) << 4); }
 
 constexpr int WS_SLAB = 128 * 128;            // one (tap, K chunk) weight slab: 128 couts x 64 cin bf16
 constexpr int WS_STORES = 16;                 // global stores per wave in the tile epilogue (4 x 4 MFMA tiles, unconditional)
 
 template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N) : "memory");
+}
+// the per-tap sync: LDS-DMA count only.  No lgkmcnt: when a wave reaches the barrier every LDS access that could conflict with what
+// the barrier releases has completed (LDS operations of a wave complete in order, and the last MFMAs consumed the last reads of the
+// slab / buffer being retired; the transform's writes precede those reads); only the next tap's prefetched fragment reads are still in
+// flight, and they read data nobody overwrites.  Their latency then overlaps the barrier wait instead of preceding it.
+template <int N> __device__ __forceinline__ void wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
 }  // namespace
@@ -119,38 +127,50 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
     }
     const size_t tap_stride = (size_t)P.Cout * P.CinPad * 2;
     const char* wbase = reinterpret_cast<const char*>(P.wp);
-    // input pieces: piece i = (u * 8 + wave) * 64 + lane -> LDS row i >> 3, position i & 7 (holds source chunk pos ^ (row & 7));
-    // recomputed from the lane id where needed (a handful of integer instructions per piece and K chunk) instead of held in registers
-    // (`l` = an OPAQUE copy of the lane id: without it the compiler hoists all of this out of the tile loop and spills it)
+    // input pieces: piece i = (u * 8 + wave) * 64 + lane -> LDS row i >> 3, position i & 7, which holds source chunk pos ^ key(row).
+    // The key is the row's COLUMN in the tile (halo: ix; whole frames: row, a multiple of 8 per image line), so that the three dx of a
+    // tap row share... each dx has one key for every dy: a tap's fragment address = a per-(pixel tile, dx) register + an immediate.
+    // Recomputed from the lane id where needed instead of held in registers (`l` = an OPAQUE copy of the lane id: without it the
+    // compiler hoists all of this out of the tile loop and spills it).
     auto piece = [&](int u, int l, int& row, int& chunk) -> bool {
         const int i = (u * 8 + wave) * 64 + l;
-        row = i >> 3; chunk = (i & 7) ^ (row & 7);
+        row = i >> 3;
+        const int key = WF ? row : row - ((row * 3641) >> 16) * IW;           // halo: ix = row % 18 (row < 324)
+        chunk = (i & 7) ^ (key & 7);
         return i < NPIECE;
     };
     auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
     const char* const zero_page = reinterpret_cast<const char*>(g_zero_page);
-    // fragment offsets: A = weight rows wc * 64 + tm * 16 + r; B = input rows of this wave's 4 x 16 pixels
-    const int aoff = frag_off(wc * 64 + r, q);
-    int hpb[4];                                           // GEO 0: halo row of the window's top-left corner; whole frames: the pixel's row
+    // fragment addresses (byte offsets into smem).  A: weight row wc * 64 + tm * 16 + r of the slab (+ tm * 2048, + slab base).
+    // B: b3[tn][dx] = chunk q of the input row under tap column dx of pixel (tn, r) for tap row 0 in buffer 0; tap row dy adds the
+    // IMMEDIATE dy * DYB, K step 1 is ^ 64, the other buffer +- HBUF (applied to the registers once per chunk).  Whole frames: a tap
+    // that leaves the frame reads the zero row instead (zs[dy] = its address minus the immediate; one v_cndmask per fragment).
+    constexpr int DYB = (WF ? S : IW) * 128;
+    const int halo_o = NS * WS_SLAB;                      // byte offset of the input buffers in smem
+    const int aoff = frag_off(wc * 64 + r, r, q);
+    int b3[4][3], zs[3];
     int opix[4];                                          // pixel offset inside the tile
-    unsigned vmask[4];                                    // whole frames: bit tap = the tap's source pixel is inside the frame
 #pragma unroll
     for (int tn = 0; tn < 4; ++tn) {
         if (!WF) {
             const int py = wpx * 4 + tn, px = r;
-            hpb[tn] = py * IW + px; opix[tn] = py * P.W + px; vmask[tn] = 0x1FFu;
-        } else {
-            const int p = wpx * 64 + tn * 16 + r, y = (p / S) % S, x = p % S;
-            hpb[tn] = p; opix[tn] = p;
-            unsigned m = 0;
+            opix[tn] = py * P.W + px;
 #pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
-                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-                m |= (yy >= 0 && yy < S && xx >= 0 && xx < S) ? (1u << tap) : 0u;
-            }
-            vmask[tn] = m;
+            for (int dx = 0; dx < 3; ++dx) b3[tn][dx] = halo_o + frag_off(py * IW + px + dx, px + dx, q);
+        } else {
+            const int p = wpx * 64 + tn * 16 + r;
+            opix[tn] = p;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) b3[tn][dx] = halo_o + frag_off(p - S - 1 + dx, p - 1 + dx, q);      // (S % 8 == 0: the key does not depend on dy)
         }
     }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) zs[dy] = halo_o + 256 * 128 + (q << 4) - dy * DYB;
+    // whole frames: is the source pixel of tap (dy, dx) of pixel (tn, r) inside the frame?  (lane masks / uniform conditions the compiler keeps in SGPRs)
+    auto tap_valid = [&](int tn, int dy, int dx) -> bool {
+        const int p = wpx * 64 + tn * 16 + r, y = (p / S) % S + dy - 1, x = p % S + dx - 1;
+        return y >= 0 && y < S && x >= 0 && x < S;
+    };
     if (tid < 128) biasl[tid] = P.bias ? P.bias[j * 128 + tid] : 0.f;      // visible after the prologue's barriers
 
     // ---- helpers ------------------------------------------------------------------------------------------------------
@@ -253,20 +273,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
             }
         }
     };
-    // fragment loads.  B row of (tn, tap): GEO 0: the halo row under the tap; whole frames: the neighbouring pixel's row, or the zero row
+    // fragment loads
     auto ldA1 = [&](int sl, int tm, int ks) -> uint4 {
         return *reinterpret_cast<const uint4*>(ring + sl * WS_SLAB + ((aoff + tm * 2048) ^ (ks * 64)));
     };
-    auto ldB = [&](uint4 (&b)[4], const int (&hp)[4], int buf, int tap, int ks) {
-        const char* hb = halo + buf * HBUF;
+    auto ldB = [&](uint4 (&b)[4], int tap, int ks) {       // from the buffer b3 / zs currently point at
         const int dy = tap / 3, dx = tap - 3 * dy;
 #pragma unroll
         for (int tn = 0; tn < 4; ++tn) {
-            int row;
-            if (WF) row = ((vmask[tn] >> tap) & 1u) ? hp[tn] + (dy - 1) * S + (dx - 1) : 256;
-            else row = hp[tn] + dy * IW + dx;
-            b[tn] = *reinterpret_cast<const uint4*>(hb + (frag_off(row, q) ^ (ks * 64)));
+            int a = b3[tn][dx];
+            if (WF) a = tap_valid(tn, dy, dx) ? a : zs[dy];
+            b[tn] = *reinterpret_cast<const uint4*>(smem + ((a ^ (ks * 64)) + dy * DYB));
         }
+    };
+    auto flip_buffers = [&](int to_buf1) {                // point b3 / zs at the other input buffer
+        const int d = to_buf1 ? HBUF : -HBUF;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) b3[tn][dx] += d;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) zs[dy] += d;
     };
 
     // ---- pipeline prologue: NS - 1 weight slabs and the first input buffer ---------------------------------------------
@@ -291,39 +318,44 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
     // weight tile, so the barrier is followed by MFMAs, not by LDS latency.  (Holding both K steps of both operands in registers,
     // 64 of them, was measured slower: r02, spills.)
     uint4 pb[4], pa;
-    ldB(pb, hpb, 0, 0, 0); pa = ldA1(0, 0, 0);
+    ldB(pb, 0, 0); pa = ldA1(0, 0, 0);
     // one K chunk = 9 taps on input buffer hbuf; (tnext, ccnext) = the buffer to fetch meanwhile.  AFTER_EPI: the 16 stores of the
     // previous tile's epilogue sit between the weight slabs in flight, so the first two syncs leave that many more operations outstanding.
     auto run_chunk = [&](auto after_epi, int tnext, int ccnext, bool xform) {
         constexpr int EPI = decltype(after_epi)::value ? WS_STORES : 0;
-        int hp[4];                                       // opaque copies: the 36 per-tap fragment offsets are recomputed (3 VALU each)
-#pragma unroll                                           // instead of being hoisted out of the tile loop into 36 live registers
-        for (int tn = 0; tn < 4; ++tn) { hp[tn] = hpb[tn]; asm volatile("" : "+v"(hp[tn])); }
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             // sync of tap: every wave's part of slab (tap + 1) has landed (issued two taps ago; at most the younger slab, and at taps
             // 0 / 1 the input pieces and the epilogue stores, may still be in flight), every wave is done with slab (tap - 1) and, at
             // tap 0, with the other input buffer; at tap 2 the input pieces issued at tap 0 (older than slab 3) have landed too
-            if (tap == 0) wait_vm_lgkm0<WIN + EPI>();
-            else if (tap == 1) wait_vm_lgkm0<WIN + NUMIN + EPI>();
-            else wait_vm_lgkm0<WIN>();
+            if (tap == 0) wait_vm<WIN + EPI>();
+            else if (tap == 1) wait_vm<WIN + NUMIN + EPI>();
+            else wait_vm<WIN>();
             __builtin_amdgcn_s_barrier();
             if (tap == 0) issue_halo(tnext, ccnext, hbuf ^ 1);
             issue_w();
-            // K step 0 on the prefetched fragments (MFMAs right behind the barrier), then K step 1, then the next tap's prefetch
+            // K step 0 on the prefetched fragments (MFMAs right behind the barrier), then K step 1, then the next tap's prefetch.
+            // Prologue work (own pieces, landed since the sync of tap 2: one per tap, done by tap 7) is STAGGERED between the two waves
+            // of a SIMD (w and w + 4): the first half transforms before its K step 0, the second half between the K steps, so one
+            // wave's VALU block runs under the other's MFMAs instead of both issuing VALU, then both MFMA, in lockstep behind the barrier
+            const bool do_x = PRO && xform && tap >= 2 && tap - 2 < NU;
+            if (do_x && wave < 4) {
+                transform(tap - 2, ccnext, hbuf ^ 1);
+                if (NU > 6 && tap == 7) transform(6, ccnext, hbuf ^ 1);
+            }
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) {
                 const uint4 a = tm == 0 ? pa : ldA1(cslot, tm, 0);
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) M::mma(acc[tm][tn], a, pb[tn]);
             }
-            if (PRO && xform && tap >= 2 && tap - 2 < NU) {      // own pieces, landed since the sync of tap 2: one per tap, done by tap 7
+            if (do_x && wave >= 4) {
                 transform(tap - 2, ccnext, hbuf ^ 1);
                 if (NU > 6 && tap == 7) transform(6, ccnext, hbuf ^ 1);
             }
             {
                 uint4 b1[4];
-                ldB(b1, hp, hbuf, tap, 1);
+                ldB(b1, tap, 1);
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm) {
                     const uint4 a = ldA1(cslot, tm, 1);
@@ -332,7 +364,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
                 }
             }
             const int nslot = (cslot + 1 == NS) ? 0 : cslot + 1;
-            ldB(pb, hp, tap == 8 ? hbuf ^ 1 : hbuf, tap == 8 ? 0 : tap + 1, 0);
+            if (tap == 8) flip_buffers(hbuf ^ 1);             // the next chunk's buffer (landed, transformed, made visible by this tap's sync)
+            ldB(pb, tap == 8 ? 0 : tap + 1, 0);
             pa = ldA1(nslot, 0, 0);
             cslot = nslot;
         }
