@@ -403,6 +403,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     float* chs = gmean + 64;                          // [2][64] channel sum / sumsq of the current sample
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int lp = lane & 15, q = lane >> 4;
     const int tiles_x = P.W >> 4, tiles_pf = tiles_x * (P.H >> 4);
     const int t0 = blockIdx.x * tiles_per_block, t1 = min(t0 + tiles_per_block, total_tiles);
@@ -430,6 +431,11 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
 
     u32x4 sreg[NU];
     unsigned okmask = 0;
+    // prologue coefficients of THIS thread's channels: every piece of a thread covers the same PCH channels (512 % PPR == 0), so they
+    // live in registers and are re-read from the LDS table only when the sample changes (r01: 16 LDS reads per piece)
+    float ca[PCH], cd[PCH];
+#pragma unroll
+    for (int k = 0; k < PCH; ++k) { ca[k] = 0.f; cd[k] = 0.f; }
     auto stage_load = [&](int t) {
         int f, ty, tx; decode(t, f, ty, tx);
         okmask = 0;
@@ -442,10 +448,11 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             sreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, int u0 = 0, int u1 = 64) {
         char* dst = Al + buf * (C64_HALO * 128);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
+            if (u < u0 || u >= u1) continue;
             if (piy[u] < 0) continue;
             const bool ok = (okmask >> u) & 1u;
             if (IN16) {
@@ -455,10 +462,8 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
                     unsigned o4[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float2 a = *reinterpret_cast<const float2*>(coefA + pch[u] + 2 * k);
-                        const float2 d = *reinterpret_cast<const float2*>(coefD + pch[u] + 2 * k);
-                        const float lo = silu_f(fmaf(__uint_as_float(w4[k] << 16), a.x, d.x));
-                        const float hi = silu_f(fmaf(__uint_as_float(w4[k] & 0xFFFF0000u), a.y, d.y));
+                        const float lo = silu_f(fmaf(__uint_as_float(w4[k] << 16), ca[2 * k], cd[2 * k]));
+                        const float hi = silu_f(fmaf(__uint_as_float(w4[k] & 0xFFFF0000u), ca[2 * k + 1], cd[2 * k + 1]));
                         o4[k] = ok ? pack_bf16x2(lo, hi) : 0u;        // zero padding stays zero AFTER the activation
                     }
                     v = u32x4{o4[0], o4[1], o4[2], o4[3]};
@@ -467,10 +472,8 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             } else {
                 float4 f = make_float4(__uint_as_float(sreg[u].x), __uint_as_float(sreg[u].y), __uint_as_float(sreg[u].z), __uint_as_float(sreg[u].w));
                 if (PRO) {
-                    const float4 a = *reinterpret_cast<const float4*>(coefA + pch[u]);
-                    const float4 d = *reinterpret_cast<const float4*>(coefD + pch[u]);
-                    f.x = ok ? silu_f(fmaf(f.x, a.x, d.x)) : 0.f; f.y = ok ? silu_f(fmaf(f.y, a.y, d.y)) : 0.f;
-                    f.z = ok ? silu_f(fmaf(f.z, a.z, d.z)) : 0.f; f.w = ok ? silu_f(fmaf(f.w, a.w, d.w)) : 0.f;
+                    f.x = ok ? silu_f(fmaf(f.x, ca[0], cd[0])) : 0.f; f.y = ok ? silu_f(fmaf(f.y, ca[1], cd[1])) : 0.f;
+                    f.z = ok ? silu_f(fmaf(f.z, ca[2], cd[2])) : 0.f; f.w = ok ? silu_f(fmaf(f.w, ca[3], cd[3])) : 0.f;
                 }
                 *reinterpret_cast<uint2*>(dst + ploff[u]) = make_uint2(pack_bf16x2(f.x, f.y), pack_bf16x2(f.z, f.w));
             }
@@ -490,6 +493,8 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             coefD[tid] = (P.beta[tid] - m * rsd * P.gamma[tid]) * sc + sh;
         }
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PCH; ++k) { ca[k] = coefA[pch[0] + k]; cd[k] = coefD[pch[0] + k]; }
     };
     // flush the register partial sums of sample b into out_stats (all threads call)
     f32x4 ssum[4], ssq[4];
@@ -552,7 +557,16 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
         const char* At = Al + buf * (C64_HALO * 128);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            if (tap == 5 && more) stage_store(buf ^ 1);       // (loading two tiles ahead instead was measured slower: r02)
+            // the next tile goes to the other buffer between the taps (loading two tiles ahead instead was measured slower: r02).
+            // With a prologue the write is VALU work (SiLU): two pieces per tap over three taps, and the two waves of a SIMD (w, w + 4)
+            // take DIFFERENT taps, so one wave's VALU block runs under the other's MFMAs instead of both stalling the matrix pipe at once
+            if (more) {
+                if (!PRO) { if (tap == 5) stage_store(buf ^ 1); }
+                else {
+                    const int first = wave_u < 4 ? 4 : 6;
+                    if (tap >= 4 && tap - first >= 0 && tap - first < 3) stage_store(buf ^ 1, 2 * (tap - first), tap - first == 2 ? NU : 2 * (tap - first) + 2);
+                }
+            }
             const int dy = tap / 3, dx = tap % 3;
             int boff[2];
 #pragma unroll
