@@ -137,10 +137,9 @@ __global__ __launch_bounds__(256) void resblock_ss_bwd_kernel(const float* __res
 // second half of the time-MLP backward, parallel over (layer, KB rows of the Linear): with dlin from the kernel above
 //   dW[k][n] += sum_b SiLU(temb[b][k]) dlin[b][n]          (coalesced over n)
 //   dtemb[b][k] += SiLU'(temb[b][k]) sum_n dlin[b][n] W[k][n]   (workgroup reduction over n, one atomic per (b, k))
-constexpr int SS_KB = 8;
 __global__ __launch_bounds__(256) void resblock_ss_bwd_w_kernel(const float* __restrict__ params, float* __restrict__ grads, const float* __restrict__ temb,
                                                                 const SsLayer* __restrict__ layers, const float* __restrict__ dss_base,
-                                                                float* __restrict__ dtemb, int temb_dim, int B) {
+                                                                float* __restrict__ dtemb, int temb_dim, int B, int SS_KB) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const SsLayer L = layers[blockIdx.x];
@@ -277,8 +276,11 @@ hipError_t launch_resblock_ss_bwd(const float* params, float* grads, const float
     hipLaunchKernelGGL(kfn, dim3(nlayers), dim3(256), lds, st, params, grads, temb, layers, lin_base, dss_base, dtemb, temb_dim, B);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(resblock_ss_bwd_w_kernel, dim3(nlayers, (temb_dim + SS_KB - 1) / SS_KB), dim3(256), 0, st, params, grads, temb, layers,
-                       dss_base, dtemb, temb_dim, B);
+    // rows of the Linear per workgroup: the per-stage launches of the staged backward cover 2 layers each (data-parallel bucket
+    // readiness, model_bwd.hip ss_bwd), so they take one row per workgroup to still fill the chip
+    const int kb = nlayers >= 8 ? 8 : 1;
+    hipLaunchKernelGGL(resblock_ss_bwd_w_kernel, dim3(nlayers, (temb_dim + kb - 1) / kb), dim3(256), 0, st, params, grads, temb, layers,
+                       dss_base, dtemb, temb_dim, B, kb);
     return hipGetLastError();
 }
 
