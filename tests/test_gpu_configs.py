@@ -220,3 +220,51 @@ def test_text_cond_768_cfg_forward_dim64(mode, tol):
     # guidance actually moves the prediction: eps(c) != eps(null)
     y1 = m.forward_with_cond_scale(x, t, cond=cond, cond_scale=1.0)
     assert _rel(y1.cpu().double(), y.cpu().double()) > 1e-4
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (e) dim = 128 (BASELINE.json configs[3]: "dim=128 Unet3D, 32-frame 128x128, DDIM-100"): level widths 128 / 256 / 512 / 1024
+# ------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('mode,tol', [('f32', 5e-5), ('bf16', 2e-2)])
+def test_dim128_forward_small_frames(mode, tol):
+    """dim 128 (the 1024-channel bottleneck: generic attention / SLA / conv paths at C = 1024) on a small video."""
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    kw = dict(dim=128, channels=3)
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=17, dtype=torch.float64)
+    m = Unet3D(rngs=0, mode=mode, **kw)
+    m.load_state_dict({k: v.float() for k, v in p.items()})
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 3, 4, 16, 16, generator=g)
+    t = torch.tensor([3, 950])
+    y = m(x, t)
+    ref = R.unet_forward(p, cfg, x.double(), t)
+    r = _rel(y.cpu().double(), ref)
+    print(f'dim128 small {mode}: rel-L2 {r:.3e}')
+    assert r < tol, r
+
+
+def test_dim128_32f_128px_ddim_shape():
+    """The full configs[3] shape, B = 1: dim 128, C = 3, 32 frames of 128 x 128.  One bf16 forward (bf16 activation storage, as the
+    sampling loops run it) against the fp32 CPU oracle, then two DDIM steps through the captured loop (finite, deterministic)."""
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    kw = dict(dim=128, channels=3)
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=19, dtype=torch.float32)
+    m = Unet3D(rngs=0, mode='bf16', **kw)
+    m.load_state_dict(p)
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(1, 3, 32, 128, 128, generator=g)
+    t = torch.tensor([500])
+    m.act_bf16 = True
+    y = m(x, t).cpu().double()
+    m.act_bf16 = False
+    ref = R.unet_forward(p, cfg, x, t).double()
+    r = _rel(y, ref)
+    print(f'dim128 32f x 128 x 128 bf16 storage: rel-L2 {r:.3e}')
+    assert r < 3e-2, r
+    gd = GaussianDiffusion(m, image_size=128, num_frames=32, channels=3, timesteps=1000)
+    a = gd.ddim_sample_loop((1, 3, 32, 128, 128), 3, steps=2)
+    assert a.shape == (1, 3, 32, 128, 128) and torch.isfinite(a).all() and 0.0 <= a.min().item() and a.max().item() <= 1.0
