@@ -245,6 +245,30 @@ def test_dim128_forward_small_frames(mode, tol):
     assert r < tol, r
 
 
+@pytest.mark.parametrize('mode,tol', [('f32', 5e-5), ('bf16', 2e-2)])
+def test_long_bottleneck_attention_96px(mode, tol):
+    """96 x 96 frames: the bottleneck spatial attention (unet3d.py:196-205) runs over 12 x 12 = 144 tokens, more than the fused
+    kernels' 64 -- the projections-as-1x1-convs + fp32 core path (attention_long_core_kernel)."""
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    from video_diffusion_nnx_amd._lib import VdxError
+    kw = dict(dim=16, channels=1)
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=23, dtype=torch.float64)
+    m = Unet3D(rngs=0, mode=mode, **kw)
+    m.load_state_dict({k: v.float() for k, v in p.items()})
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 1, 3, 96, 96, generator=g)
+    t = torch.tensor([100, 800])
+    taps = {}
+    y = m(x, t)
+    ref = R.unet_forward(p, cfg, x.double(), t, taps=taps)
+    got = m.slot('mid_spatial_attn', 2, 3, 96).cpu().double().reshape(taps['mid_spatial_attn'].shape)
+    assert _rel(got, taps['mid_spatial_attn']) < tol
+    assert _rel(y.cpu().double(), ref) < tol
+    with pytest.raises(VdxError):                            # the backward of this block is not served: must fail loudly, not silently
+        m.backward(torch.ones_like(y), torch.zeros_like(m.flat_params))
+
+
 def test_dim128_32f_128px_ddim_shape():
     """The full configs[3] shape, B = 1: dim 128, C = 3, 32 frames of 128 x 128.  One bf16 forward (bf16 activation storage, as the
     sampling loops run it) against the fp32 CPU oracle, then two DDIM steps through the captured loop (finite, deterministic)."""

@@ -797,6 +797,7 @@ static hipError_t launch_attn_reg(const AttnArgs& a, hipStream_t st) {
     if (a.C <= 128) return launch_attn_reg_t<MODE, 8>(a, st);
     if (a.C <= 256) return launch_attn_reg_t<MODE, 16>(a, st);
     if (a.C <= 512) return launch_attn_reg_t<MODE, 32>(a, st);
+    if (a.C <= 1024) return launch_attn_reg_t<MODE, 64>(a, st);
     return hipErrorInvalidValue;
 }
 
@@ -823,6 +824,7 @@ static hipError_t launch_attn_l(const AttnArgs& a, hipStream_t st) {
     if (a.C <= 128) return launch_attn_t<MODE, LP, 2>(a, st);
     if (a.C <= 256) return launch_attn_t<MODE, LP, 4>(a, st);
     if (a.C <= 512) return launch_attn_t<MODE, LP, 8>(a, st);
+    if (a.C <= 1024) return launch_attn_t<MODE, LP, 16>(a, st);
     return hipErrorInvalidValue;
 }
 
@@ -842,11 +844,67 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
         if (a.C == 64 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 2, false>(a, st);
         if (a.C == 128 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 4, false>(a, st);
     }
-    if (a.L <= 16 && use_reg) return launch_attn_reg<MODE>(a, st);
+    if (a.L <= 16 && use_reg && !(MODE == MODE_F32 && a.C > 512)) return launch_attn_reg<MODE>(a, st);    // (f32 weight tiles of C = 1024 exceed the LDS: staged form)
     if (a.L <= 16) return launch_attn_l<MODE, 16>(a, st);
     if (a.L <= 32) return launch_attn_l<MODE, 32>(a, st);
     if (a.L <= 64) return launch_attn_l<MODE, 64>(a, st);
     return hipErrorInvalidValue;
+}
+
+// ---- long sequences (L > 64: the bottleneck spatial attention of frames larger than 64 x 64, e.g. 16 x 16 = 256 tokens at 128 x 128) ----
+// The projections run as 1x1 convs (model.hip); this is the core: one workgroup per (sequence, head), one query row per thread, K and V
+// of the head in LDS (every lane reads the same key: broadcast), online softmax in fp32 VALU -- exact in both arithmetic modes.  The
+// block is ONE launch per forward with ~3 GFLOP at B = 1, so it is written for correctness, not for the matrix cores.
+// qkv [rows][3 * heads * 32] fp32 (biased, q unscaled; modules.py:261-271,294), o [rows][heads * 32] fp32; rows = nseq * L, token-major.
+__global__ __launch_bounds__(256) void attention_long_core_kernel(const float* __restrict__ qkv, float* __restrict__ o, int L, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float kv[];          // K [L][32] | V [L][32]
+    const int seq = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const int HD = heads * 32;
+    const float* base = qkv + (size_t)seq * L * 3 * HD;
+    float* Ks = kv; float* Vs = kv + (size_t)L * 32;
+    for (int i = tid; i < L * 8; i += 256) {
+        const int j = i >> 3, c = (i & 7) * 4;
+        *reinterpret_cast<float4*>(Ks + j * 32 + c) = *reinterpret_cast<const float4*>(base + (size_t)j * 3 * HD + HD + h * 32 + c);
+        *reinterpret_cast<float4*>(Vs + j * 32 + c) = *reinterpret_cast<const float4*>(base + (size_t)j * 3 * HD + 2 * HD + h * 32 + c);
+    }
+    __syncthreads();
+    for (int row = tid; row < L; row += 256) {
+        float q[32], acc[32];
+#pragma unroll
+        for (int c = 0; c < 32; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(base + (size_t)row * 3 * HD + h * 32 + c);
+            q[c] = v.x * scale; q[c + 1] = v.y * scale; q[c + 2] = v.z * scale; q[c + 3] = v.w * scale;      // q /= sqrt(d) (modules.py:294)
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+        float m = -3.0e38f, l = 0.f;
+        for (int j = 0; j < L; ++j) {
+            float sdot = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) sdot = fmaf(q[c], Ks[j * 32 + c], sdot);
+            const float mn = fmaxf(m, sdot), corr = __expf(m - mn), pj = __expf(sdot - mn);
+            l = l * corr + pj;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) acc[c] = fmaf(pj, Vs[j * 32 + c], acc[c] * corr);
+            m = mn;
+        }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int c = 0; c < 32; c += 4)
+            *reinterpret_cast<float4*>(o + ((size_t)seq * L + row) * HD + h * 32 + c) = make_float4(acc[c] * inv, acc[c + 1] * inv, acc[c + 2] * inv, acc[c + 3] * inv);
+    }
+}
+
+hipError_t launch_attention_long_core(const float* qkv, float* o, long nseq, int L, int heads, float scale, hipStream_t st) {
+    const size_t lds = (size_t)L * 64 * 4;
+    if (lds > 160 * 1024 || nseq <= 0 || nseq >= (1L << 31)) return hipErrorInvalidValue;            // L <= 640 tokens
+    auto kfn = attention_long_core_kernel;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nseq, heads), dim3(256), lds, st, qkv, o, L, heads, scale);
+    return hipGetLastError();
 }
 
 hipError_t launch_attention(int mode, AttnArgs a, hipStream_t st) {

@@ -263,6 +263,10 @@ int model_build(Model* m) {
         if (c.dim * c.dim_mults[l] >= 256)
             m->sla_ws_bytes_per_sample = std::max(m->sla_ws_bytes_per_sample, (size_t)F * s * s * c.attn_heads * 32 * 2);
     }
+    {   // bottleneck spatial attention over more than 64 tokens (frames larger than 64 x 64): materialised qkv + o, fp32
+        const long s = c.image_size >> (nl - 1);
+        if (s * s > 64) m->sla_ws_bytes_per_sample = std::max(m->sla_ws_bytes_per_sample, (size_t)F * s * s * c.attn_heads * 32 * 4 * 4);
+    }
     return VDX_OK;
 }
 
@@ -401,6 +405,29 @@ static hipError_t run_attn(const Fwd& f, const AttnP& ap, const float* x, float*
     if (temporal) { a.L = (int)Fr; a.nseq = f.B * hw; a.inner = hw; a.inner_stride = ap.C; a.outer_stride = Fr * hw * ap.C; a.tok_stride = hw * ap.C; }
     else { a.L = (int)hw; a.nseq = f.B * Fr; a.inner = 1; a.inner_stride = 0; a.outer_stride = hw * ap.C; a.tok_stride = ap.C; }
     a.io_bf16 = f.a16;
+    if (a.L > 64) {
+        // long sequences (spatial attention of a bottleneck larger than 8 x 8): q|k|v projection and out-projection (+ bias + residual)
+        // as 1x1 convs around the fp32 core of attention.hip; token-major rows = the channel-last tensor as it is
+        if (temporal) return hipErrorInvalidValue;                       // (a temporal axis of more than 64 frames is not served)
+        const int HD = a.heads * 32;
+        float* qkv = reinterpret_cast<float*>(f.sla_ws);
+        float* o = qkv + (size_t)f.B * Fr * hw * 3 * HD;
+        ConvArgs p;
+        memset(&p, 0, sizeof(p));
+        p.x0 = x; p.C0 = ap.C; p.x0_bf16 = f.a16; p.wp = f.pk + ap.pk_qkv; p.bias = reinterpret_cast<const float*>(f.pk + ap.pk_bqkv);
+        p.y = qkv; p.Cout = 3 * HD;
+        p.NF = f.B * (int)Fr; p.F = (int)Fr; p.H = (int)S; p.W = (int)S; p.kind = 0; p.kh = p.kw = 1; p.stride = 1; p.pad = 0;
+        hipError_t e = launch_conv(m->mode, p, f.st);
+        if (e != hipSuccess) return e;
+        e = launch_attention_long_core(qkv, o, a.nseq, a.L, a.heads, a.scale, f.st);
+        if (e != hipSuccess) return e;
+        ConvArgs c;
+        memset(&c, 0, sizeof(c));
+        c.x0 = o; c.C0 = HD; c.wp = f.pk + ap.pk_o; c.bias = f.p + ap.o_b; c.y = y; c.Cout = ap.C; c.y_bf16 = f.a16;
+        c.res = x; c.res_bf16 = f.a16;
+        c.NF = f.B * (int)Fr; c.F = (int)Fr; c.H = (int)S; c.W = (int)S; c.kind = 0; c.kh = c.kw = 1; c.stride = 1; c.pad = 0;
+        return launch_conv(m->mode, c, f.st);
+    }
     // wide levels in bf16 mode: per-head kernel (weights resident in LDS) + the out-projection as a 1x1 conv
     const int use_heads = 1;
     if (use_heads && m->mode == MODE_BF16 && temporal && a.L <= 16 && a.heads == 8 && ap.C >= 256 && ap.C % 128 == 0 &&

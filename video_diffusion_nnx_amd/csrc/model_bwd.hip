@@ -242,6 +242,11 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
     const int nl = c.n_mults, top = 2 * nl + 2;
     if (stage_hi > top || stage_lo < 0 || stage_lo > stage_hi) return vdx_set_error(VDX_ERR_INVALID, "backward: bad stage range", __FILE__, __LINE__);
     if (bwd_workspace_bytes < model_bwd_workspace_bytes(m, B)) return vdx_set_error(VDX_ERR_NOMEM, "backward: workspace too small", __FILE__, __LINE__);
+    {
+        const long sb = c.image_size >> (c.n_mults - 1);
+        if (sb * sb > 64 || c.num_frames > 64)
+            return vdx_set_error(VDX_ERR_INVALID, "backward: attention over more than 64 tokens (frames larger than 64 x 64, or more than 64 frames) is forward-only", __FILE__, __LINE__);
+    }
     if (stage_hi != top && state->next_stage != stage_hi) return vdx_set_error(VDX_ERR_STATE, "backward: stages must be run in descending order from the head", __FILE__, __LINE__);
     Bwd b;
     b.m = m; b.p = params; b.pk = reinterpret_cast<const char*>(packed); b.pt = reinterpret_cast<const char*>(packed_t);

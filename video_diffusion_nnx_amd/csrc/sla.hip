@@ -951,6 +951,7 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
     if (a.C <= 128) return launch_sla_out_t<MODE, 2>(a, st);
     if (a.C <= 256) return launch_sla_out_t<MODE, 4>(a, st);
     if (a.C <= 512) return launch_sla_out_t<MODE, 8>(a, st);
+    if (a.C <= 1024) return launch_sla_out_t<MODE, 16>(a, st);     // dim 128: the 1024-channel bottleneck level
     return hipErrorInvalidValue;
 }
 

@@ -86,6 +86,9 @@ hipError_t launch_attention(int mode, AttnArgs a, hipStream_t st);
 // bf16 mode, <= 16 tokens, 8 heads: q/k/v projection + attention core per head (one workgroup per head: its weights resident in LDS,
 // every wave streams its own sequences, no barriers) -> a.oscratch; the out-projection + residual is a 1x1 conv_igemm by the caller
 hipError_t launch_attention_heads(AttnArgs a, hipStream_t st);
+// sequences of more than 64 tokens (token-major rows): softmax(q k^T / sqrt(d)) v per (sequence, head) from a materialised
+// qkv [rows][3 * heads * 32] fp32 into o [rows][heads * 32] fp32; the projections are 1x1 convs by the caller
+hipError_t launch_attention_long_core(const float* qkv, float* o, long nseq, int L, int heads, float scale, hipStream_t st);
 
 // y = SpatialLinearAttention(x) + x, x/y channel-last [NF][N][C]; 8 heads x 32
 struct SlaArgs {
