@@ -19,6 +19,7 @@ groups=(
 )
 i=0
 for g in "${groups[@]}"; do
+  if [ -n "$PMC_GROUPS" ] && [[ " $PMC_GROUPS " != *" $i "* ]]; then i=$((i+1)); continue; fi      # PMC_GROUPS="0 3": only those counter groups
   d=$out/g$i; mkdir -p $d
   timeout -k 10 150 rocprofv3 --pmc $g --output-format csv -d $d -- python3 $root/$tool > $d/log.txt 2>&1 || echo "group $i failed: $(tail -2 $d/log.txt | tr '\n' ' ')"
   i=$((i+1))
