@@ -40,8 +40,10 @@ typedef enum {
 
 /* Arithmetic of the MFMA contractions (activations and master weights are fp32 in HBM either way):
  *   VDX_MODE_F32  exact fp32 products (v_mfma_f32_16x16x4_f32)  -- the parity mode
- *   VDX_MODE_BF16 operands rounded to bf16 at LDS staging, fp32 accumulate (v_mfma_f32_16x16x32_bf16) */
-typedef enum { VDX_MODE_F32 = 0, VDX_MODE_BF16 = 1 } vdx_mode;
+ *   VDX_MODE_BF16 operands rounded to bf16 at LDS staging, fp32 accumulate (v_mfma_f32_16x16x32_bf16)
+ *   VDX_MODE_F16  operands rounded to IEEE fp16 at LDS staging, fp32 accumulate (v_mfma_f32_16x16x32_f16): the "fp16" of
+ *                 BASELINE.json configs[3]; generic kernels only (every tensor stays fp32 in HBM, no bf16 activation storage) */
+typedef enum { VDX_MODE_F32 = 0, VDX_MODE_BF16 = 1, VDX_MODE_F16 = 2 } vdx_mode;
 
 const char* vdx_last_error(void);
 int vdx_version(void);

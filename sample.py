@@ -1,7 +1,7 @@
 """Sampling CLI for the MI355X path.  Accepts the reference CLI's flags (reference sample.py:19-62: --config,
 --output-path, --checkpoint-path, --step, --seed, --batch-size, --load-ema-params) and its YAML schema, then runs
 GaussianDiffusion.sample on the GPU and writes one GIF per video (batch-global min-max to uint8, 120 ms/frame).
-Extensions: --mode {bf16,f32}; --random-init (no checkpoint); --timesteps N (shorter chain for smoke runs)."""
+Extensions: --mode {bf16,f16,f32}; --random-init (no checkpoint); --timesteps N (shorter chain for smoke runs); --ddim-steps S."""
 import argparse
 import logging
 import pathlib
@@ -17,9 +17,10 @@ FLAGS = (   # (flag, kwargs)
     ('--seed', dict(type=int, default=0, help='Philox seed of the sampling chain')),
     ('--batch-size', dict(type=int, default=2, help='videos to draw')),
     ('--load-ema-params', dict(action='store_true', help='sample from the EMA weights')),
-    ('--mode', dict(choices=('bf16', 'f32'), default='bf16', help='MFMA operand precision')),
+    ('--mode', dict(choices=('bf16', 'f16', 'f32'), default='bf16', help='MFMA operand precision')),
     ('--random-init', dict(action='store_true', help='skip the checkpoint, use freshly initialised weights')),
     ('--timesteps', dict(type=int, default=None, help='override diffusion.timesteps')),
+    ('--ddim-steps', dict(type=int, default=None, help='sample with an S-step DDIM chain (eta = 0) instead of the T-step ancestral one')),
 )
 
 
@@ -56,7 +57,7 @@ def main(argv=None):
         ckpt = pathlib.Path(a.checkpoint_path).resolve()
         gd, _ = load_checkpoint(gd, a.step, str(ckpt), load_ema_params=a.load_ema_params)
         logging.info('restored step %d from %s', a.step, ckpt)
-    videos = gd.sample(a.seed, batch_size=a.batch_size)
+    videos = gd.sample(a.seed, batch_size=a.batch_size, ddim_steps=a.ddim_steps)
     logging.info('drew %d videos', len(videos))
     for i, frames in enumerate(videos_to_uint8(videos.cpu().numpy())):
         target = out_dir / f'sample_{i}.gif'

@@ -292,3 +292,84 @@ def test_dim128_32f_128px_ddim_shape():
     gd = GaussianDiffusion(m, image_size=128, num_frames=32, channels=3, timesteps=1000)
     a = gd.ddim_sample_loop((1, 3, 32, 128, 128), 3, steps=2)
     assert a.shape == (1, 3, 32, 128, 128) and torch.isfinite(a).all() and 0.0 <= a.min().item() and a.max().item() <= 1.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (f) fp16 operand mode (VDX_MODE_F16; the "fp16" of BASELINE.json configs[3]): forward, CFG, backward, one DDIM chain
+# ------------------------------------------------------------------------------------------------------------------
+
+def _f16r(t):
+    return t.to(torch.float16).to(torch.float32)
+
+
+def test_f16_conv_exact_products():
+    """conv_igemm in fp16 operand mode: operands rounded to fp16, exact products, fp32 accumulate (same contract as bf16 mode)."""
+    from video_diffusion_nnx_amd import ops
+    dev = torch.device('cuda:0')
+    for (B, Fr, S, cin, cout, k, stride, kind) in [(1, 4, 16, 32, 64, 3, 1, 0), (1, 2, 8, 64, 128, 4, 2, 0), (1, 2, 8, 32, 32, 4, 1, 1), (1, 3, 6, 48, 40, 1, 1, 0)]:
+        g = torch.Generator().manual_seed(cin + cout)
+        x = torch.randn(B, Fr, S, S, cin, generator=g)
+        kern = torch.randn(1, k, k, cin, cout, generator=g) / (k * k * cin) ** 0.5
+        bias = torch.randn(cout, generator=g)
+        pw = ops.pack_conv_weights(kern.to(dev), 'f16')
+        y = ops.conv_forward(x.to(dev), pw, cout, mode='f16', bias=bias.to(dev), kind=kind, k=k, stride=stride)
+        xr, kr = _f16r(x).double(), _f16r(kern).double()
+        ref = (R.conv_transpose_144(xr, kr, bias.double()) if kind == 1 else R.conv_pointwise(xr, kr[0], bias.double()) if k == 1
+               else R.conv_1kk(xr, kr, bias.double(), stride=stride))
+        assert _rel(y.cpu().double(), ref) < 2e-6, (cin, cout, k)
+
+
+@pytest.mark.parametrize('kw,shape', [
+    (dict(dim=16, channels=3, cond_dim=32), (2, 3, 4, 16, 16)),
+    (dict(dim=64, channels=1), (1, 1, 5, 32, 32)),
+    (dict(dim=16, channels=1, dim_mults=(1, 2), use_sparse_linear_attn=False), (1, 1, 3, 8, 8)),
+])
+def test_f16_unet_forward_and_backward(kw, shape):
+    """fp16 operands: eps rel-L2 vs the fp64 oracle ~1e-3 (3 more mantissa bits than bf16's 7e-3); gradients through the generic
+    backward (fp16 data-gradient convs, exact-f32 weight gradients and attention cores).  Stated: 4e-3 forward, 1.5e-2 backward."""
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    cfg = R.UnetConfig(**kw)
+    p64 = R.random_params(cfg, seed=7, dtype=torch.float64)
+    m = Unet3D(rngs=0, mode='f16', **kw)
+    m.load_state_dict({k: v.float() for k, v in p64.items()})
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g)
+    t = torch.randint(0, 1000, (shape[0],), generator=g)
+    cond = torch.randn(shape[0], cfg.cond_in, generator=g) if cfg.has_cond else None
+    y = m(x, t, cond=cond)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p64.items()}
+    ref_out = R.unet_forward(leaves, cfg, x.double(), t, cond=None if cond is None else cond.double())
+    r = _rel(y.cpu().double(), ref_out.detach())
+    print(f'f16 forward {kw}: rel-L2 {r:.3e}')
+    assert r < 4e-3, r
+    d_out = torch.randn(y.shape, generator=g)
+    grads = torch.zeros_like(m.flat_params)
+    m.backward(d_out.to(m.device), grads)
+    ref = torch.autograd.grad(ref_out, list(leaves.values()), d_out.double(), allow_unused=True)
+    ref_grads = {k: (torch.zeros_like(v) if gr is None else gr) for (k, v), gr in zip(leaves.items(), ref)}
+    rg = _rel(_got_flat(m, grads), _flat(m, ref_grads))
+    print(f'f16 backward {kw}: rel-L2 {rg:.3e}')
+    assert rg < 1.5e-2, rg
+    with pytest.raises(ValueError):                          # bf16 activation storage belongs to bf16 mode
+        m.act_bf16 = True
+        m(x, t, cond=cond)
+    m.act_bf16 = False
+
+
+def test_f16_ddim_chain():
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    kw = dict(dim=16, channels=1, dim_mults=(1, 2))
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=2, dtype=torch.float64)
+    unet = Unet3D(rngs=0, mode='f16', **kw)
+    unet.load_state_dict({k: v.float() for k, v in p.items()})
+    T, S, shape = 60, 12, (2, 1, 4, 8, 8)
+    gd = GaussianDiffusion(unet, image_size=8, num_frames=4, channels=1, timesteps=T)
+    out = gd.ddim_sample_loop(shape, 11, steps=S)
+    x_T = torch.from_numpy(philox_ref.randn(int(np.prod(shape)), 11, 0)).double().reshape(shape)
+    ref = DiffusionRef(lambda a, b: R.unet_forward(p, cfg, a, b), image_size=8, num_frames=4, channels=1, timesteps=T, dtype=torch.float64)
+    exp = (ref.ddim_sample_loop(x_T, S) + 1) * 0.5
+    err = ((out.cpu().double() - exp).norm() / exp.norm()).item()
+    print(f'f16 DDIM-{S} chain rel-L2 {err:.3e}')
+    assert err < 2e-2, err

@@ -16,7 +16,7 @@ FLAGS = (
     ('--config', dict(type=str, default=str(HERE / 'configs' / 'config.yaml'), help='YAML with unet / diffusion / trainer sections')),
     ('--resume_step', dict(type=int, default=0, help='restore params + EMA of this step first (optimizer state restarts)')),
     ('--rng_seed', dict(type=int, default=None, help='master seed; default: config rng_seed, else 0')),
-    ('--mode', dict(choices=('bf16', 'f32'), default='bf16', help='MFMA operand precision')),
+    ('--mode', dict(choices=('bf16', 'f16', 'f32'), default='bf16', help='MFMA operand precision')),
     ('--train_num_steps', dict(type=int, default=None, help='override trainer.train_num_steps')),
     ('--dataset_path', dict(type=str, default=None, help='override trainer.dataset_path')),
 )

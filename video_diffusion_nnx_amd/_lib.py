@@ -13,7 +13,9 @@ LIB_PATH = os.path.join(_HERE, 'libvdx.so')
 
 MODE_F32 = 0
 MODE_BF16 = 1
-MODES = {'f32': MODE_F32, 'fp32': MODE_F32, 'float32': MODE_F32, 'bf16': MODE_BF16, 'bfloat16': MODE_BF16}
+MODE_F16 = 2
+MODES = {'f32': MODE_F32, 'fp32': MODE_F32, 'float32': MODE_F32, 'bf16': MODE_BF16, 'bfloat16': MODE_BF16,
+         'f16': MODE_F16, 'fp16': MODE_F16, 'float16': MODE_F16}
 GN_SLOTS = 32
 
 

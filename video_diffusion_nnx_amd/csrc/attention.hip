@@ -834,6 +834,7 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
     const bool use_h8 = true;        // debugging switch: skip the one-wave-per-head kernel
     const bool h8_ok = a.L <= 16 && a.heads == 8 && a.inner % 4 == 0 && a.nseq % 4 == 0 && a.nseq < (1L << 31) &&
                        3 * a.inner_stride + 15 * a.tok_stride + a.C < (1L << 31);
+    if constexpr (MODE != MODE_F16) {                  // (the one-wave-per-head kernels hard-code the bf16 / f32 register formats)
     if (h8_ok && use_reg && use_h8) {
         const int nkt = a.CPad / Mma<MODE>::KT;
         if constexpr (MODE == MODE_BF16) {
@@ -843,6 +844,7 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
         if (a.C == 64 && nkt == 1) return launch_attn_h8_t<MODE, 1, 1, 2, false>(a, st);
         if (a.C == 64 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 2, false>(a, st);
         if (a.C == 128 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 4, false>(a, st);
+    }
     }
     if (a.L <= 16 && use_reg && !(MODE == MODE_F32 && a.C > 512)) return launch_attn_reg<MODE>(a, st);    // (f32 weight tiles of C = 1024 exceed the LDS: staged form)
     if (a.L <= 16) return launch_attn_l<MODE, 16>(a, st);
@@ -910,7 +912,7 @@ hipError_t launch_attention_long_core(const float* qkv, float* o, long nseq, int
 hipError_t launch_attention(int mode, AttnArgs a, hipStream_t st) {
     a.CPad = conv_cin_pad(mode, a.C);
     a.HDPad = conv_cin_pad(mode, a.heads * 32);
-    return mode == MODE_F32 ? launch_attn_m<MODE_F32>(a, st) : launch_attn_m<MODE_BF16>(a, st);
+    return mode == MODE_F32 ? launch_attn_m<MODE_F32>(a, st) : mode == MODE_F16 ? launch_attn_m<MODE_F16>(a, st) : launch_attn_m<MODE_BF16>(a, st);
 }
 
 }  // namespace vdx

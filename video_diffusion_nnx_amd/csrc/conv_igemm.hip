@@ -814,8 +814,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ src, void* __restr
         const int co = (int)(r % Cout);
         const int t = (int)(r / Cout);
         const float v = (ci < Cin) ? src[((size_t)t * Cin + ci) * Cout + co] : 0.f;
-        if (MODE == MODE_F32) reinterpret_cast<float*>(dst)[i] = v;
-        else reinterpret_cast<__bf16*>(dst)[i] = (__bf16)v;
+        store_operand<MODE>(dst, i, v);
     }
 }
 
@@ -831,8 +830,7 @@ __global__ void pack_weights_t_kernel(const float* __restrict__ src, void* __res
         const int ci = (int)(r % Cin);
         const int t = (int)(r / Cin);
         const float v = (co < Cout) ? src[((size_t)(taps - 1 - t) * Cin + ci) * Cout + co] : 0.f;
-        if (MODE == MODE_F32) reinterpret_cast<float*>(dst)[i] = v;
-        else reinterpret_cast<__bf16*>(dst)[i] = (__bf16)v;
+        store_operand<MODE>(dst, i, v);
     }
 }
 
@@ -865,7 +863,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const float* __restrict_
                 if (co < J.Cout && kk < J.Pad) {
                     const size_t di = ((size_t)t * J.Cout + co) * J.Pad + kk;
                     const float v = tile[tx][ty + 8 * j];
-                    if (MODE == MODE_F32) reinterpret_cast<float*>(dstc)[di] = v; else reinterpret_cast<__bf16*>(dstc)[di] = (__bf16)v;
+                    store_operand<MODE>(dstc, di, v);
                 }
             }
             __syncthreads();
@@ -881,14 +879,14 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const float* __restrict_
             const float* srow = src + ((size_t)(J.taps - 1 - t) * J.Cin + ci) * J.Cout;
             for (int k = threadIdx.x; k < J.Pad; k += 256) {
                 const float v = (k < J.Cout) ? srow[k] : 0.f;
-                if (MODE == MODE_F32) reinterpret_cast<float*>(dstc)[drow + k] = v; else reinterpret_cast<__bf16*>(dstc)[drow + k] = (__bf16)v;
+                store_operand<MODE>(dstc, drow + k, v);
             }
         } else {                                              // kind 3: row = input channel, k = (tensor, output channel) of three kernels
             for (int k = threadIdx.x; k < J.Pad; k += 256) {
                 const int sel = k / J.Cout, kk = k - sel * J.Cout;
                 const float* sp = params + (sel == 0 ? J.src : (sel == 1 ? J.src1 : J.src2));
                 const float v = (sel < 3) ? sp[(size_t)r * J.Cout + kk] : 0.f;
-                if (MODE == MODE_F32) reinterpret_cast<float*>(dstc)[drow + k] = v; else reinterpret_cast<__bf16*>(dstc)[drow + k] = (__bf16)v;
+                store_operand<MODE>(dstc, drow + k, v);
             }
         }
     }
@@ -929,6 +927,7 @@ hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, 
     const size_t n = (size_t)taps * Cout * CinPad;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
     if (mode == MODE_F32) hipLaunchKernelGGL(pack_weights_kernel<MODE_F32>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CinPad);
+    else if (mode == MODE_F16) hipLaunchKernelGGL(pack_weights_kernel<MODE_F16>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CinPad);
     else hipLaunchKernelGGL(pack_weights_kernel<MODE_BF16>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CinPad);
     return hipGetLastError();
 }
@@ -937,6 +936,7 @@ hipError_t launch_pack_jobs(int mode, const float* params, void* dst_base, const
     if (njobs <= 0) return hipSuccess;
     dim3 grid(96, njobs);
     if (mode == MODE_F32) hipLaunchKernelGGL(pack_jobs_kernel<MODE_F32>, grid, dim3(256), 0, st, params, reinterpret_cast<char*>(dst_base), d_jobs);
+    else if (mode == MODE_F16) hipLaunchKernelGGL(pack_jobs_kernel<MODE_F16>, grid, dim3(256), 0, st, params, reinterpret_cast<char*>(dst_base), d_jobs);
     else hipLaunchKernelGGL(pack_jobs_kernel<MODE_BF16>, grid, dim3(256), 0, st, params, reinterpret_cast<char*>(dst_base), d_jobs);
     return hipGetLastError();
 }
@@ -946,6 +946,7 @@ hipError_t launch_pack_weights_t(int mode, const float* src, void* dst, int taps
     const size_t n = (size_t)taps * Cin * CoutPad;
     const int blocks = (int)std::min<size_t>((n + 255) / 256, 2048);
     if (mode == MODE_F32) hipLaunchKernelGGL(pack_weights_t_kernel<MODE_F32>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CoutPad);
+    else if (mode == MODE_F16) hipLaunchKernelGGL(pack_weights_t_kernel<MODE_F16>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CoutPad);
     else hipLaunchKernelGGL(pack_weights_t_kernel<MODE_BF16>, dim3(blocks), dim3(256), 0, st, src, dst, taps, Cin, Cout, CoutPad);
     return hipGetLastError();
 }
@@ -1013,6 +1014,9 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     } while (0)
     if (mode == MODE_F32) {
         if (inf == 0) VDX_LAUNCH_CONV_T(MODE_F32, 0); else VDX_LAUNCH_CONV_T(MODE_F32, 3);
+    } else if (mode == MODE_F16) {
+        if (inf != 0) return hipErrorInvalidValue;           // fp16 operand mode keeps every tensor fp32 in HBM
+        VDX_LAUNCH_CONV_T(MODE_F16, 0);
     } else {
         if (inf == 0) VDX_LAUNCH_CONV_T(MODE_BF16, 0); else if (inf == 1) VDX_LAUNCH_CONV_T(MODE_BF16, 1);
         else if (inf == 2) VDX_LAUNCH_CONV_T(MODE_BF16, 2); else VDX_LAUNCH_CONV_T(MODE_BF16, 3);

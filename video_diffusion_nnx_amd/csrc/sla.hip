@@ -931,6 +931,7 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
     a.ctxT = reinterpret_cast<char*>(a.workspace) + part_bytes;
     const bool generic_only = false;
     const int nkt = a.CPad / M::KT;
+    if constexpr (MODE != MODE_F16)                           // (the one-wave-per-head kernels hard-code the bf16 / f32 register formats)
     if (a.heads == 8 && a.C % 64 == 0 && !generic_only) {     // one wave per head; x tile double-buffered in LDS
         if constexpr (MODE == MODE_BF16) {
             if (a.io_bf16 && a.C == 64) return launch_sla8_t<MODE, 1, 1, 2, true>(a, st);
@@ -957,7 +958,7 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
 
 hipError_t launch_sla(int mode, SlaArgs a, hipStream_t st) {
     a.CPad = conv_cin_pad(mode, a.C);
-    return mode == MODE_F32 ? launch_sla_m<MODE_F32>(a, st) : launch_sla_m<MODE_BF16>(a, st);
+    return mode == MODE_F32 ? launch_sla_m<MODE_F32>(a, st) : mode == MODE_F16 ? launch_sla_m<MODE_F16>(a, st) : launch_sla_m<MODE_BF16>(a, st);
 }
 
 }  // namespace vdx

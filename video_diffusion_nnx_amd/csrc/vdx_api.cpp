@@ -67,7 +67,7 @@ size_t vdx_packed_conv_bytes(int mode, int taps, int cin, int cout) { return vdx
 
 int vdx_pack_conv_weights(int mode, const float* kernel, void* packed, int taps, int cin, int cout, void* stream) {
     if (!kernel || !packed || taps <= 0 || cin <= 0 || cout <= 0) VDX_FAIL(VDX_ERR_INVALID, "pack_conv_weights: bad argument");
-    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
+    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16 && mode != VDX_MODE_F16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
     VDX_HIP(vdx::launch_pack_weights(mode, kernel, packed, taps, cin, cout, (hipStream_t)stream));
     return VDX_OK;
 }
@@ -76,7 +76,7 @@ size_t vdx_gn_stats_bytes(int batch, int groups) { return (size_t)batch * 32 /*G
 
 int vdx_conv_forward(int mode, const vdx_conv_desc* d, void* stream) {
     if (!d || !d->x0 || !d->packed_w || !d->y) VDX_FAIL(VDX_ERR_INVALID, "conv: null tensor");
-    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
+    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16 && mode != VDX_MODE_F16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
     if (d->c0 % 4 || d->c1 % 4 || d->cout % 4) VDX_FAIL(VDX_ERR_INVALID, "conv: channel counts must be multiples of 4");
     if (d->c1 && !d->x1) VDX_FAIL(VDX_ERR_INVALID, "conv: x1 missing");
     if (d->batch <= 0 || d->frames <= 0 || d->h <= 0 || d->w <= 0) VDX_FAIL(VDX_ERR_INVALID, "conv: bad geometry");
@@ -159,7 +159,7 @@ int vdx_attention_forward(int mode, const float* x, float* y, const void* wqkv_p
                           const void* wo_packed, const float* bo, int batch, int frames, int h, int w, int c, int heads,
                           int temporal, void* stream) {
     if (!x || !y || !wqkv_packed || !bqkv || !wo_packed || !bo) VDX_FAIL(VDX_ERR_INVALID, "attention: null tensor");
-    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
+    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16 && mode != VDX_MODE_F16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
     if (c % 4 || c > 512 || heads < 1) VDX_FAIL(VDX_ERR_INVALID, "attention: C must be a multiple of 4 and <= 512");
     vdx::AttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -181,7 +181,7 @@ size_t vdx_sla_workspace_bytes(int mode, int nframes, int npix, int heads) { ret
 int vdx_sla_forward(int mode, const float* x, float* y, const void* wq_packed, const void* wk_packed, const void* wv_packed,
                     const void* wo_packed, void* workspace, int batch, int frames, int h, int w, int c, int heads, void* stream) {
     if (!x || !y || !wq_packed || !wk_packed || !wv_packed || !wo_packed || !workspace) VDX_FAIL(VDX_ERR_INVALID, "sla: null tensor");
-    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
+    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16 && mode != VDX_MODE_F16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
     if (heads != 8 || c % 4 || c > 512) VDX_FAIL(VDX_ERR_INVALID, "sla: needs 8 heads, C multiple of 4 and <= 512");
     vdx::SlaArgs a;
     memset(&a, 0, sizeof(a));
@@ -193,7 +193,7 @@ int vdx_sla_forward(int mode, const float* x, float* y, const void* wq_packed, c
 
 int vdx_create(const vdx_config* cfg, vdx_handle** out) {
     if (!cfg || !out) VDX_FAIL(VDX_ERR_INVALID, "create: null argument");
-    if (cfg->mode != VDX_MODE_F32 && cfg->mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
+    if (cfg->mode != VDX_MODE_F32 && cfg->mode != VDX_MODE_BF16 && cfg->mode != VDX_MODE_F16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
     vdx_handle* h = new vdx_handle();
     h->model.cfg = *cfg;
     int rc = vdx::model_build(&h->model);
@@ -421,7 +421,7 @@ int vdx_ddim_sample_loop(vdx_handle* h, const float* params, const void* packed,
 
 int vdx_pack_conv_weights_t(int mode, const float* kernel, void* packed, int taps, int cin, int cout, void* stream) {
     if (!kernel || !packed || taps <= 0 || cin <= 0 || cout <= 0) VDX_FAIL(VDX_ERR_INVALID, "pack_conv_weights_t: bad argument");
-    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
+    if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16 && mode != VDX_MODE_F16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
     VDX_HIP(vdx::launch_pack_weights_t(mode, kernel, packed, taps, cin, cout, (hipStream_t)stream));
     return VDX_OK;
 }

@@ -7,6 +7,7 @@
 // 64-byte CHUNKS.  Lane l = (r = l & 15, q = l >> 4) reads the 16 bytes [16q, 16q+16) of row r of a
 // chunk with ONE ds_read_b128 for either operand:
 //   MODE_BF16: 16 B = 8 bf16 = k {8q..8q+7} of a 32-deep chunk  -> one v_mfma_f32_16x16x32_bf16
+//   MODE_F16 : as MODE_BF16 with IEEE half operands (v_mfma_f32_16x16x32_f16): 3 more mantissa bits, 5-bit exponent
 //   MODE_F32 : 16 B = 4 f32  = k {4q..4q+3} of a 16-deep chunk  -> four v_mfma_f32_16x16x4_f32,
 //              step s pairing element s of both fragments (k = 4q+s: a permutation of the
 //              reduction order shared by A and B, so the dot product is unchanged).
@@ -20,7 +21,7 @@
 
 namespace vdx {
 
-enum { MODE_F32 = 0, MODE_BF16 = 1 };
+enum { MODE_F32 = 0, MODE_BF16 = 1, MODE_F16 = 2 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -103,6 +104,49 @@ template <> struct Mma<MODE_BF16> {
         *reinterpret_cast<__bf16*>(row + k * 2) = h;
     }
 };
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pack_f16x2(float a, float b) {
+    f32x2 v = {a, b};
+    f16x2 r = __builtin_convertvector(v, f16x2);     // v_cvt_f16_f32 (RNE)
+    return __builtin_bit_cast(unsigned, r);
+}
+
+// fp16 operands (the "fp16" of BASELINE.json configs[3]): same fragment geometry as bf16.  Activations and weights of this network
+// stay far inside the fp16 range (GroupNorm / LayerNorm keep them O(1..10)); values beyond 65504 would saturate to inf.
+template <> struct Mma<MODE_F16> {
+    static constexpr int ES = 2;
+    static constexpr int KC = 32;
+    static constexpr int KT = 64;
+    static __device__ __forceinline__ void mma(f32x4& acc, const uint4& a, const uint4& b) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ void mma16(f32x4& acc, const f32x4& a, const f32x4& b) {
+        const uint2 ua = make_uint2(pack_f16x2(a[0], a[1]), pack_f16x2(a[2], a[3]));
+        const uint2 ub = make_uint2(pack_f16x2(b[0], b[1]), pack_f16x2(b[2], b[3]));
+        acc = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4, ua), __builtin_bit_cast(f16x4, ub), acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 load_w4(const char* p) {
+        const f16x4 h = *reinterpret_cast<const f16x4*>(p);
+        return f32x4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    }
+    static __device__ __forceinline__ void store4(char* row, int k, float4 v) {
+        *reinterpret_cast<uint2*>(row + k * 2) = make_uint2(pack_f16x2(v.x, v.y), pack_f16x2(v.z, v.w));
+    }
+    static __device__ __forceinline__ void store1(char* row, int k, float v) {
+        *reinterpret_cast<_Float16*>(row + k * 2) = (_Float16)v;
+    }
+};
+
+// one packed-weight element of the mode's operand type
+template <int MODE> __device__ __forceinline__ void store_operand(void* dst, size_t i, float v) {
+    if (MODE == MODE_F32) reinterpret_cast<float*>(dst)[i] = v;
+    else if (MODE == MODE_BF16) reinterpret_cast<__bf16*>(dst)[i] = (__bf16)v;
+    else reinterpret_cast<_Float16*>(dst)[i] = (_Float16)v;
+}
 
 // 4 consecutive channels of a tensor stored as fp32 or bf16 (element index i, a multiple of 4)
 __device__ __forceinline__ float4 load4_f32_or_bf16(const float* base, size_t i, int is_bf16) {

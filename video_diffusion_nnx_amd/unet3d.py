@@ -111,7 +111,7 @@ def _trunc_normal(rng: np.random.Generator, shape, std: float) -> np.ndarray:
 class Unet3D:
     """Space-time factorised 3-D U-Net denoiser (reference unet3d.py:58-75 signature).
 
-    Extra keyword `mode` ('bf16' | 'f32') selects the MFMA arithmetic; `device` the GPU.
+    Extra keyword `mode` ('bf16' | 'f16' | 'f32') selects the MFMA arithmetic; `device` the GPU.
     """
 
     def __init__(self, dim: int, rngs=0, dim_mults=(1, 2, 4, 8), cond_dim=None, out_dim=None, channels=3,
