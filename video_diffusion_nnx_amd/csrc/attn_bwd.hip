@@ -9,7 +9,7 @@
 
 namespace vdx {
 
-// one workgroup = one sequence of L <= 64 tokens, loop over heads.  qkv [npix][3*HD] (+bias, q unscaled), dO [npix][HD]
+// one workgroup = one (sequence, head) of L <= 64 tokens (blockIdx.y = head).  qkv [npix][3*HD] (+bias, q unscaled), dO [npix][HD]
 // -> O, dq, dk, dv [npix][HD] each.  Token t of sequence s is pixel row (s / inner) * outer_p + (s % inner) + t * tok_p.
 __global__ __launch_bounds__(256) void attn_core_bwd_kernel(AttnBwdArgs P) {
     extern __shared__ float sm[];
@@ -21,8 +21,8 @@ __global__ __launch_bounds__(256) void attn_core_bwd_kernel(AttnBwdArgs P) {
     const long s = blockIdx.x;
     const long row0 = (s / P.inner) * P.outer_p + (s % P.inner);
     const int HD = P.heads * 32;
-    for (int h = 0; h < P.heads; ++h) {
-        __syncthreads();
+    {
+        const int h = blockIdx.y;
         for (int i = tid; i < L * 32; i += 256) {
             const int t = i >> 5, d = i & 31;
             const size_t row = (size_t)(row0 + (long)t * P.tok_p);
@@ -589,7 +589,7 @@ hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)a.nseq), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)a.nseq, (unsigned)a.heads), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 

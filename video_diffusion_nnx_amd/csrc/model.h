@@ -56,7 +56,14 @@ size_t model_bwd_workspace_bytes(const Model* m, int B);
 hipError_t model_pack_t(const Model* m, const float* params, void* packed_t, hipStream_t st);
 // Reverse pass over stages [stage_lo, stage_hi] (descending; 2n+2 = head ... 0 = stem).  A full pass calls the stages in
 // order; `state` carries the running activation gradient between calls.
-struct BwdState { float* g = nullptr; int next_stage = -1; };
+// `side`: the handle's second stream for the weight-gradient kernels (leaves of the reverse graph: they run beside the data-gradient
+// chain of the caller's stream; model_bwd.hip) + a ring of events for the fork / join edges.  Created on first use, freed by bwd_state_free.
+constexpr int BWD_EVENTS = 64;
+struct BwdState {
+    float* g = nullptr; int next_stage = -1;
+    hipStream_t side = nullptr; hipEvent_t ev[BWD_EVENTS] = {}; int ev_next = 0;
+};
+void bwd_state_free(BwdState* s);
 int model_backward(const Model* m, BwdState* state, const float* params, const void* packed, const void* packed_t, const float* x,
                    const int* time, const float* cond, const unsigned char* cond_mask, int null_all, const float* d_out,
                    void* fwd_workspace, void* bwd_workspace, size_t bwd_workspace_bytes, float* grads, int stage_hi, int stage_lo,

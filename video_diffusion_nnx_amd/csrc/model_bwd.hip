@@ -14,7 +14,8 @@ namespace vdx {
 
 namespace {
 
-struct LevelBufs { float* ga; float* gb; float* t1; float* t2; float* t3; float* gskip; };
+struct LevelBufs { float* ga; float* gb; float* t1; float* t2; float* t3; float* t4; float* gskip; };
+constexpr int LVL_BUFS = 7;
 
 struct Bwd {
     const Model* m; const float* p; const char* pk; const char* pt; float* grads; int B; hipStream_t st;
@@ -28,6 +29,35 @@ struct Bwd {
     int size(int lvl) const { return m->cfg.image_size >> lvl; }
     hipError_t err = hipSuccess;
     bool ok(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; return e == hipSuccess; }
+
+    // ---- second stream ------------------------------------------------------------------------------------------------------
+    // Weight gradients are leaves of the reverse graph: nothing of the pass reads them, so they run on the handle's side stream
+    // beside the data-gradient chain (at batch 4 per GPU most kernels leave CUs or wave slots idle; DESIGN.md, backward).
+    // Edges: a side launch waits for everything enqueued on the main stream so far (side()); the main stream waits for the side
+    // stream before it overwrites a buffer a pending side kernel reads (writes()), and at the end of every stage (join()): a
+    // stage's parameter gradients are final when the stage returns, as the data-parallel reducer assumes.
+    BwdState* state = nullptr;
+    std::vector<const void*> pending;               // buffers read by side kernels the main stream has not waited for
+    bool main_dirty = true;
+    hipEvent_t next_event() { hipEvent_t e = state->ev[state->ev_next]; state->ev_next = (state->ev_next + 1) % BWD_EVENTS; return e; }
+    hipStream_t side(const void* r0, const void* r1 = nullptr) {
+        if (!state->side) return st;
+        if (main_dirty) { hipEvent_t e = next_event(); ok(hipEventRecord(e, st)); ok(hipStreamWaitEvent(state->side, e, 0)); main_dirty = false; }
+        if (r0) pending.push_back(r0);
+        if (r1) pending.push_back(r1);
+        return state->side;
+    }
+    void join() {
+        if (pending.empty()) return;
+        hipEvent_t e = next_event(); ok(hipEventRecord(e, state->side)); ok(hipStreamWaitEvent(st, e, 0));
+        pending.clear();
+    }
+    // the main stream is about to launch a kernel that writes w0 / w1
+    hipStream_t writes(const void* w0, const void* w1 = nullptr) {
+        for (const void* p : pending) if (p == w0 || (w1 && p == w1)) { join(); break; }
+        main_dirty = true;
+        return st;
+    }
 };
 
 // widest tensor a level's backward buffers hold: its own width, or the width of the level that feeds it (the input gradient of
@@ -49,7 +79,7 @@ void dgrad(Bwd& b, const float* dy, int Cdy, const void* wpt, int rows_total, in
     if (kind_fwd == 0 && stride_fwd == 1) { a.H = a.W = b.size(lvl_in); a.kind = 0; a.kh = a.kw = k; a.stride = 1; a.pad = (k - 1) / 2; }
     else if (kind_fwd == 0) { a.H = a.W = b.size(lvl_in + 1); a.kind = 1; a.kh = a.kw = 4; a.stride = 1; }                      // Downsample -> ConvTranspose
     else { a.H = a.W = b.size(lvl_in - 1); a.kind = 0; a.kh = a.kw = 4; a.stride = 2; a.pad = 1; }                               // Upsample -> stride-2 conv
-    b.ok(launch_conv(b.m->mode, a, b.st));
+    b.ok(launch_conv(b.m->mode, a, b.writes(out)));
 }
 
 void wgrad(Bwd& b, const float* x0, int c0, const float* x1, int c1, const float* dy, int Cout, long w_off, long b_off, int lvl_in, int kind, int k, int stride,
@@ -61,10 +91,9 @@ void wgrad(Bwd& b, const float* x0, int c0, const float* x1, int c1, const float
     a.kind = kind; a.kh = a.kw = kind ? 4 : k; a.stride = kind ? 1 : stride;
     a.bf16_mma = (b.m->mode == MODE_BF16);
     if (in_stats) { a.x0_bf16 = (b.m->mode == MODE_BF16); a.pro = 1; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta; a.groups = b.m->cfg.resnet_groups; a.ss = ss; a.ss_stride = ss_stride; }
-    b.ok(launch_conv_wgrad(a, b.st));
+    b.ok(launch_conv_wgrad(a, b.side(dy)));
 }
 
-void colsum(Bwd& b, const float* x, long rows, int C, long off) { b.ok(launch_colsum(x, b.grads + off, rows, C, b.st)); }
 
 // ResnetBlock backward.  g = dL/d(out) [pix][cout]; writes dL/d(x0) to out0 ([pix][c0]) and dL/d(x1) to out1 ([pix][c1], if c1)
 void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, const float* x1, int c1, int lvl, float* out0, float* out1) {
@@ -81,32 +110,32 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     t.r = rsrc; t.ln_gamma = b.p + r.n2_s; t.dr = L.t2; t.d_ln_gamma = b.grads + r.n2_s; t.d_ln_beta = b.grads + r.n2_b;
     // R at a fixed offset of the scratch: zeroed once per backward, the finalize pass leaves it zero again
     t.G = b.normscr; t.R = b.normscr + (size_t)b.B * 64; t.r_clean = 1; t.C = r.cout; t.batch = b.B; t.pix_per_sample = b.pix(lvl);
-    b.ok(launch_norm_bwd(t, b.st));
-    // 2. conv2: y2 = conv(SiLU(GN1(y1)*(1+s)+sh))
+    b.ok(launch_norm_bwd(t, b.writes(L.t1, L.t2)));
+    // 2. conv2: y2 = conv(SiLU(GN1(y1)*(1+s)+sh)); the weight gradients that only need the tail's outputs go to the side stream now
     const float* ssrow = r.has_mlp ? b.ss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
     wgrad(b, b.slot(r.s_y1), r.cout, nullptr, 0, L.t1, r.cout, r.b2_w, r.b2_b, lvl, 0, 3, 1, b.stat(r.st1), b.p + r.b1_gs, b.p + r.b1_gb, ssrow, 2 * r.cout);
+    if (r.has_res) wgrad(b, x0, c0, x1, c1, L.t2, r.cout, r.rc_w, r.rc_b, lvl, 0, 1, 1);
     dgrad(b, L.t1, r.cout, b.pt + r.pt_b2, r.cout, 0, r.cout, lvl, 0, 3, 1, nullptr, L.t3);            // dL/d(act1)
     // 3. prologue: act1 = SiLU((GN1(y1))*(1+s)+sh)
     NormBwdArgs q;
     memset(&q, 0, sizeof(q));
-    q.dact = L.t3; q.y = b.slot(r.s_y1); q.y_bf16 = (m->mode == MODE_BF16); q.dy = L.t1; q.stats = b.stat(r.st1); q.gamma = b.p + r.b1_gs; q.beta = b.p + r.b1_gb; q.groups = G;
+    q.dact = L.t3; q.y = b.slot(r.s_y1); q.y_bf16 = (m->mode == MODE_BF16); q.dy = L.t4; q.stats = b.stat(r.st1); q.gamma = b.p + r.b1_gs; q.beta = b.p + r.b1_gb; q.groups = G;
     q.ss = ssrow; q.ss_stride = 2 * r.cout; q.d_gamma = b.grads + r.b1_gs; q.d_beta = b.grads + r.b1_gb;
     q.dss = r.has_mlp ? b.dss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
     q.G = b.normscr; q.R = b.normscr + (size_t)b.B * 64; q.r_clean = 1; q.C = r.cout; q.batch = b.B; q.pix_per_sample = b.pix(lvl);
-    b.ok(launch_norm_bwd(q, b.st));                                                                    // t1 = dL/d(y1)
+    b.ok(launch_norm_bwd(q, b.writes(L.t4)));                                                           // t4 = dL/d(y1) (not t1: conv2's weight gradient may still be reading it)
     // 4. conv1 + residual branch
-    wgrad(b, x0, c0, x1, c1, L.t1, r.cout, r.b1_w, r.b1_b, lvl, 0, 3, 1);
+    wgrad(b, x0, c0, x1, c1, L.t4, r.cout, r.b1_w, r.b1_b, lvl, 0, 3, 1);
     const int cin = c0 + c1;
     if (r.has_res) {
-        wgrad(b, x0, c0, x1, c1, L.t2, r.cout, r.rc_w, r.rc_b, lvl, 0, 1, 1);
         dgrad(b, L.t2, r.cout, b.pt + r.pt_rc, cin, 0, c0, lvl, 0, 1, 1, nullptr, L.t3);
-        dgrad(b, L.t1, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t3, out0);
+        dgrad(b, L.t4, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t3, out0);
         if (c1) {
             dgrad(b, L.t2, r.cout, b.pt + r.pt_rc, cin, c0, c1, lvl, 0, 1, 1, nullptr, L.t3);
-            dgrad(b, L.t1, r.cout, b.pt + r.pt_b1, cin, c0, c1, lvl, 0, 3, 1, L.t3, out1);
+            dgrad(b, L.t4, r.cout, b.pt + r.pt_b1, cin, c0, c1, lvl, 0, 3, 1, L.t3, out1);
         }
     } else {
-        dgrad(b, L.t1, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t2, out0);                   // identity residual: + dL/d(r)
+        dgrad(b, L.t4, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t2, out0);                   // identity residual: + dL/d(r)
     }
 }
 
@@ -119,7 +148,7 @@ void proj(Bwd& b, const float* x, int cin, const void* wp, const float* bias, in
     a.x0 = x; a.C0 = cin; a.wp = wp; a.bias = bias; a.y = y; a.Cout = cout; a.res = res; a.x0_bf16 = x_bf16; a.y_bf16 = y_bf16;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1; a.pad = 0;
-    b.ok(launch_conv(b.m->mode, a, b.st));
+    b.ok(launch_conv(b.m->mode, a, b.writes(y)));
 }
 
 void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w_off, long b_off, int lvl, int x_bf16 = 0) {
@@ -130,7 +159,7 @@ void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
     a.bf16_mma = (b.m->mode == MODE_BF16);
-    b.ok(launch_conv_wgrad(a, b.st));
+    b.ok(launch_conv_wgrad(a, b.side(b.S, dy)));                   // x = O lives in the attention scratch
 }
 
 // the q, k and v projection weight gradients of one block in ONE launch: dy = [rows][dq | dk | dv], x read once
@@ -144,7 +173,7 @@ void wgrad1x1_qkv(Bwd& b, const float* x, int cin, const float* dqkv, int hd, co
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
     a.bf16_mma = (b.m->mode == MODE_BF16);
-    b.ok(launch_conv_wgrad(a, b.st));
+    b.ok(launch_conv_wgrad(a, b.side(b.S)));                       // dq | dk | dv live in the attention scratch
 }
 
 // y = MHA(x) + x  backward: g = dL/dy -> out = dL/dx
@@ -157,6 +186,7 @@ void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, 
     // their fp32-sized places in the scratch
     const long hw = (long)b.size(lvl) * b.size(lvl), Fr = m->cfg.num_frames;
     const int io16 = (m->mode == MODE_BF16 && (temporal ? Fr : hw) <= 16) ? 1 : 0;
+    b.writes(b.S);                                                 // the scratch is rewritten from here on
     proj(b, x, C, b.pk + ap.pk_qkv, reinterpret_cast<const float*>(b.pk + ap.pk_bqkv), 3 * HD, lvl, nullptr, qkv, 0, io16);
     proj(b, g, C, b.pt + ap.pt_o, nullptr, HD, lvl, nullptr, dO, 0, io16);                           // dO = g . Wo^T
     AttnBwdArgs a;
@@ -168,7 +198,7 @@ void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, 
     if (temporal) { a.L = (int)Fr; a.nseq = b.B * hw; a.inner = hw; a.outer_p = Fr * hw; a.tok_p = hw; }
     else { a.L = (int)hw; a.nseq = b.B * Fr; a.inner = 1; a.outer_p = hw; a.tok_p = 1; }
     a.bf16_mma = (m->mode == MODE_BF16);
-    b.ok(launch_attn_core_bwd(a, b.st));
+    b.ok(launch_attn_core_bwd(a, b.writes(b.S)));
     wgrad1x1(b, O, HD, g, C, ap.o_w, ap.o_b, lvl, io16);
     wgrad1x1_qkv(b, x, C, dq, HD, ap.w, ap.b, lvl, io16);
     proj(b, dq, 3 * HD, b.pt + ap.pt_qkv, nullptr, C, lvl, g, out, io16, 0);                          // dx = g + [dq|dk|dv] . [Wq;Wk;Wv]^T
@@ -181,6 +211,7 @@ void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, fl
     float* q = b.S; float* k = q + npix * HD; float* v = k + npix * HD; float* dOut = v + npix * HD; float* O = dOut + npix * HD;
     float* dq = O + npix * HD;      // [npix][dq | dk | dv]
     const int io16 = (m->mode == MODE_BF16) ? 1 : 0;      // bf16 mode: q, k, v, dOut, O and dq|dk|dv are bf16 tensors in fp32-sized scratch places
+    b.writes(b.S);
     proj(b, x, C, b.pk + sp.pk[0], nullptr, HD, lvl, nullptr, q, 0, io16);
     proj(b, x, C, b.pk + sp.pk[1], nullptr, HD, lvl, nullptr, k, 0, io16);
     proj(b, x, C, b.pk + sp.pk[2], nullptr, HD, lvl, nullptr, v, 0, io16);
@@ -192,7 +223,7 @@ void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, fl
     else { a.dk = dq + HD; a.dv = dq + 2 * HD; }
     a.NF = b.B * m->cfg.num_frames; a.N = b.size(lvl) * b.size(lvl); a.heads = m->cfg.attn_heads;
     a.bf16_mma = (m->mode == MODE_BF16);
-    b.ok(launch_sla_bwd(a, b.st));
+    b.ok(launch_sla_bwd(a, b.writes(b.S)));
     wgrad1x1(b, O, HD, g, C, sp.o_w, -1, lvl, io16);
     wgrad1x1_qkv(b, x, C, dq, HD, sp.w, nullptr, lvl, io16);
     proj(b, dq, 3 * HD, b.pt + sp.pt_qkv, nullptr, C, lvl, g, out, io16, 0);
@@ -205,10 +236,15 @@ float* other(const LevelBufs& L, const float* cur) { return cur == L.ga ? L.gb :
 // all-reduces a bucket as soon as its last stage has been enqueued); d(temb) accumulates across stages and is consumed by the stem.
 void ss_bwd(Bwd& b, int first, int count) {
     if (first < 0 || count <= 0) return;
-    b.ok(launch_resblock_ss_bwd(b.p, b.grads, b.temb, b.m->d_ss_layers + first, count, b.ss_lin, b.dss, b.dtemb, b.m->temb_dim, b.B, b.st));
+    b.ok(launch_resblock_ss_bwd(b.p, b.grads, b.temb, b.m->d_ss_layers + first, count, b.ss_lin, b.dss, b.dtemb, b.m->temb_dim, b.B, b.writes(nullptr)));
 }
 
 }  // namespace
+
+void bwd_state_free(BwdState* s) {
+    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); s->side = nullptr; }
+    for (int i = 0; i < BWD_EVENTS; ++i) if (s->ev[i]) { (void)hipEventDestroy(s->ev[i]); s->ev[i] = nullptr; }
+}
 
 static size_t al(size_t floats) { return (floats + 63) / 64 * 64; }
 
@@ -217,7 +253,7 @@ size_t model_bwd_workspace_bytes(const Model* m, int B) {
     size_t fl = 0;
     for (int l = 0; l < nl; ++l) {
         const long s = m->cfg.image_size >> l;
-        fl += 6 * al((size_t)B * m->cfg.num_frames * s * s * lvl_width(m, l));
+        fl += LVL_BUFS * al((size_t)B * m->cfg.num_frames * s * s * lvl_width(m, l));
     }
     const size_t pix0 = (size_t)B * m->cfg.num_frames * m->cfg.image_size * m->cfg.image_size;
     fl += al(pix0 * m->init_dim);                                  // gr
@@ -250,7 +286,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
     if (stage_hi != top && state->next_stage != stage_hi) return vdx_set_error(VDX_ERR_STATE, "backward: stages must be run in descending order from the head", __FILE__, __LINE__);
     Bwd b;
     b.m = m; b.p = params; b.pk = reinterpret_cast<const char*>(packed); b.pt = reinterpret_cast<const char*>(packed_t);
-    b.grads = grads; b.B = B; b.st = st;
+    b.grads = grads; b.B = B; b.st = st; b.state = state;
     {   // forward workspace carve (must match model_forward)
         char* w = reinterpret_cast<char*>(fwd_workspace);
         b.act = reinterpret_cast<float*>(w); w += ((size_t)m->act_floats_per_sample * B * 4 + 255) / 256 * 256;
@@ -265,7 +301,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
         for (int l = 0; l < nl; ++l) {
             const long s = c.image_size >> l;
             const size_t n = al((size_t)B * c.num_frames * s * s * lvl_width(m, l));
-            b.lv[l].ga = w; w += n; b.lv[l].gb = w; w += n; b.lv[l].t1 = w; w += n; b.lv[l].t2 = w; w += n; b.lv[l].t3 = w; w += n; b.lv[l].gskip = w; w += n;
+            b.lv[l].ga = w; w += n; b.lv[l].gb = w; w += n; b.lv[l].t1 = w; w += n; b.lv[l].t2 = w; w += n; b.lv[l].t3 = w; w += n; b.lv[l].t4 = w; w += n; b.lv[l].gskip = w; w += n;
         }
         const size_t pix0 = (size_t)B * c.num_frames * c.image_size * c.image_size;
         b.gr = w; w += al(pix0 * m->init_dim);
@@ -276,6 +312,11 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
         b.sla_a = w;
     }
     hipError_t e;
+    if (!state->side) {
+        if (hipStreamCreateWithFlags(&state->side, hipStreamNonBlocking) != hipSuccess) return vdx_set_error(VDX_ERR_HIP, "backward: side stream", __FILE__, __LINE__);
+        for (int i = 0; i < BWD_EVENTS; ++i)
+            if (hipEventCreateWithFlags(&state->ev[i], hipEventDisableTiming) != hipSuccess) return vdx_set_error(VDX_ERR_HIP, "backward: events", __FILE__, __LINE__);
+    }
 #define VDX_E(x) do { e = (x); if (e != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); } while (0)
     const long pix0 = b.pix(0) * B;
     float* g = state->g;
@@ -288,7 +329,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             VDX_E(hipMemsetAsync(b.normscr, 0, (size_t)B * (2 * 1024 + 64) * 4, st));
             // head: out = conv1x1(fin(concat(x_up, r)))
             const Level& U = m->ups[nl - 1];
-            VDX_E(launch_final_conv_bwd(b.slot(m->fin.s_out), d_out, params + m->fin_w, b.lv[0].ga, grads + m->fin_w, grads + m->fin_b, pix0, c.dim, m->out_dim, st));
+            VDX_E(launch_final_conv_bwd(b.slot(m->fin.s_out), d_out, params + m->fin_w, b.lv[0].ga, grads + m->fin_w, grads + m->fin_b, pix0, c.dim, m->out_dim, b.writes(b.lv[0].ga)));
             res_bwd(b, m->fin, b.lv[0].ga, b.slot(U.s_attn), U.cout, b.slot(m->s_init_attn), m->init_dim, 0, b.lv[0].gb, b.gr);
             g = b.lv[0].gb;
         } else if (stage >= nl + 2) {
@@ -333,7 +374,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
                 dgrad(b, g, L.cout, b.pt + L.pt_rs, L.cout, 0, L.cout, i, 0, 4, 2, LB.gskip, LB.ga);      // + skip gradient
                 g = LB.ga;
             } else {
-                VDX_E(launch_add_inplace(g, LB.gskip, b.pix(i) * B * L.cout, st));
+                VDX_E(launch_add_inplace(g, LB.gskip, b.pix(i) * B * L.cout, b.writes(g)));
             }
             const float* attn_in = L.has_sla ? b.slot(L.s_sla) : b.slot(L.res1.s_out);
             float* o = other(LB, g);
@@ -348,18 +389,19 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
         } else {
             // stem: r gradient joins, init temporal attention, init conv, time-embedding MLPs
             LevelBufs& LB = b.lv[0];
-            VDX_E(launch_add_inplace(g, b.gr, pix0 * m->init_dim, st));
+            VDX_E(launch_add_inplace(g, b.gr, pix0 * m->init_dim, b.writes(g)));
             float* o = other(LB, g);
             attn_bwd(b, m->init_attn, g, b.slot(m->s_init), 0, true, o); g = o;
             VDX_E(launch_init_conv_wgrad(x, g, grads + m->init_w, grads + m->init_b, B, c.channels, c.num_frames, c.image_size, c.image_size,
-                                         m->init_dim, c.init_kernel_size, st));
+                                         m->init_dim, c.init_kernel_size, b.side(g)));
             TimeMlpArgs t;
             memset(&t, 0, sizeof(t));
             t.time = time; t.w1 = params + m->t_w1; t.b1 = params + m->t_b1; t.w2 = params + m->t_w2; t.b2 = params + m->t_b2;
             t.dim = c.dim; t.time_dim = m->time_dim; t.cond = cond; t.cond_mask = cond_mask; t.null_all = null_all; t.cond_dim = c.cond_dim; t.temb_dim = m->temb_dim;
             VDX_E(launch_time_mlp_bwd(t, b.dtemb, grads + m->t_w1, grads + m->t_b1, grads + m->t_w2, grads + m->t_b2,
-                                      c.cond_dim ? grads + m->null_cond : nullptr, B, st));
+                                      c.cond_dim ? grads + m->null_cond : nullptr, B, b.writes(nullptr)));
         }
+        b.join();                                                  // every gradient of the stage is final on `st`
         if (b.err != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(b.err), __FILE__, __LINE__);
     }
 #undef VDX_E

@@ -223,6 +223,7 @@ int vdx_create(const vdx_config* cfg, vdx_handle** out) {
 void vdx_destroy(vdx_handle* h) {
     if (!h) return;
     h->drop_graphs();
+    vdx::bwd_state_free(&h->bwd);
     if (h->model.d_ss_layers) (void)hipFree(h->model.d_ss_layers);
     if (h->model.d_pack_jobs) (void)hipFree(h->model.d_pack_jobs);
     if (h->model.d_pack_t_jobs) (void)hipFree(h->model.d_pack_t_jobs);
