@@ -197,6 +197,199 @@ __global__ __launch_bounds__(256) void attn_core_bwd16_kernel(AttnBwdArgs P) {
     }
 }
 
+// ---- fused form for the temporal attention of the widest level (bf16 mode, C == 64, 8 heads, <= 16 tokens) ------------------
+// At level 0 the q|k|v tensor is 12x the block input, so the unfused chain (q/k/v recompute -> dO projection -> core -> dx projection)
+// moves ~2.7 GB per block at batch 4; here one wave owns a sequence, keeps its x and g rows as MFMA B fragments, and per head
+//   q^T, k^T, v^T = W_h x^T + b (A = rows of the packed forward weights, resident in LDS for the whole workgroup), dO^T = Wo_h^T g^T
+//   -> the four wave-private [token][32] images of attn_core_bwd16_kernel -> the same core
+//   dx^T += W_q,h^T dq^T + W_k,h^T dk^T + W_v,h^T dv^T    (A = transposing reads of the SAME weight image, B = the packed outputs)
+// and writes O and dq|dk|dv (bf16) only for the weight-gradient kernels: x, g in (134 MB), O, dq|dk|dv, dx out.
+constexpr int AX_RSW = 64 * 2 + 16;          // bytes per row of the weight image (conflict-free for the row and the transposing reads)
+
+__device__ __forceinline__ uint4 pack8u_bf16(const float4& a, const float4& b) {
+    return make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+}
+
+__global__ __launch_bounds__(512, 2) void attn_bwd16x_kernel(AttnBwdXArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Wi = smem;                                                  // [768 = (part, head, d)][AX_RSW]: K = input channel
+    float* bias = reinterpret_cast<float*>(Wi + 768 * AX_RSW);         // [768]
+    char* imgs = reinterpret_cast<char*>(bias + 768);                 // [8 waves][4 images][16][AB_RS]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lp = lane & 15, q = lane >> 4;
+    for (int i = tid; i < 768 * 8; i += 512) {
+        const int row = i >> 3, c = i & 7;
+        *reinterpret_cast<uint4*>(Wi + row * AX_RSW + c * 16) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wqkv) + (size_t)row * 128 + c * 16);
+    }
+    for (int i = tid; i < 768; i += 512) bias[i] = P.bqkv[i];
+    __syncthreads();
+    char* img = imgs + w * (4 * 16 * AB_RS);
+    char* Qi = img; char* Ki = Qi + 16 * AB_RS; char* Vi = Ki + 16 * AB_RS; char* Di = Vi + 16 * AB_RS;
+    const int troff = (4 * q + (lp >> 2)) * AB_RS + (lp & 3) * 8;      // transposing reads of the images (attn_core_bwd16_kernel)
+    const int trW = (4 * q + (lp >> 2)) * AX_RSW + (lp & 3) * 8;       // ... of a 16-row group of the weight image
+    const bool tvalid = lp < P.L;
+    const float SL2E = P.scale * 1.44269504088896f;
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    const char* woT = reinterpret_cast<const char*>(P.woT);
+    for (long s = (long)blockIdx.x * 8 + w; s < P.nseq; s += (long)gridDim.x * 8) {     // (wave-uniform trip count: EXEC stays full)
+        const long row0 = (s / P.inner) * P.outer_p + (s % P.inner);
+        const size_t prow = (size_t)(row0 + (long)lp * P.tok_p);       // this lane's token row
+        // x and g rows of token lp as B fragments: K step ks covers channels 32 ks + 8 q .. + 7
+        uint4 xf[2], gf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
+            if (tvalid) {
+                const float* xp = P.x + prow * 64 + ks * 32 + 8 * q;
+                const float* gp = P.g + prow * 64 + ks * 32 + 8 * q;
+                a = *reinterpret_cast<const float4*>(xp); b = *reinterpret_cast<const float4*>(xp + 4);
+                c = *reinterpret_cast<const float4*>(gp); d = *reinterpret_cast<const float4*>(gp + 4);
+            }
+            xf[ks] = pack8u_bf16(a, b); gf[ks] = pack8u_bf16(c, d);
+        }
+        f32x4 dxT[4] = {z, z, z, z};                                   // dx^T: rows = channels 16 ct + 4q + e, column = token lp
+#pragma unroll 1
+        for (int h = 0; h < 8; ++h) {
+            // ---- projections of this head: accumulator rows = d (16 t + 4q + e), column = token lp ----
+            f32x4 qT[2], kT[2], vT[2], dT[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 bq = *reinterpret_cast<const float4*>(bias + h * 32 + t * 16 + 4 * q);
+                const float4 bk = *reinterpret_cast<const float4*>(bias + 256 + h * 32 + t * 16 + 4 * q);
+                const float4 bv = *reinterpret_cast<const float4*>(bias + 512 + h * 32 + t * 16 + 4 * q);
+                qT[t] = f32x4{bq.x, bq.y, bq.z, bq.w}; kT[t] = f32x4{bk.x, bk.y, bk.z, bk.w}; vT[t] = f32x4{bv.x, bv.y, bv.z, bv.w};
+                dT[t] = z;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const char* wr = Wi + (h * 32 + t * 16 + lp) * AX_RSW + ks * 64 + q * 16;
+                    const bf16x8 aq = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wr));
+                    const bf16x8 ak = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wr + 256 * AX_RSW));
+                    const bf16x8 av = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wr + 512 * AX_RSW));
+                    const bf16x8 ao = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(woT + ((size_t)(h * 32 + t * 16 + lp) * 64 + ks * 32 + q * 8) * 2));
+                    const bf16x8 xb = __builtin_bit_cast(bf16x8, xf[ks]), gb = __builtin_bit_cast(bf16x8, gf[ks]);
+                    qT[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, xb, qT[t], 0, 0, 0);
+                    kT[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, xb, kT[t], 0, 0, 0);
+                    vT[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, xb, vT[t], 0, 0, 0);
+                    dT[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ao, gb, dT[t], 0, 0, 0);
+                }
+            // ---- the four images: row = token lp, 4 channels 16 t + 4q .. (tokens past L: zero rows, as the unfused staging) ----
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int co = (t * 16 + 4 * q) * 2;
+                const uint2 zz = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2*>(Qi + lp * AB_RS + co) = tvalid ? __builtin_bit_cast(uint2, pack4_bf16(qT[t])) : zz;
+                *reinterpret_cast<uint2*>(Ki + lp * AB_RS + co) = tvalid ? __builtin_bit_cast(uint2, pack4_bf16(kT[t])) : zz;
+                *reinterpret_cast<uint2*>(Vi + lp * AB_RS + co) = tvalid ? __builtin_bit_cast(uint2, pack4_bf16(vT[t])) : zz;
+                *reinterpret_cast<uint2*>(Di + lp * AB_RS + co) = __builtin_bit_cast(uint2, pack4_bf16(dT[t]));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- core (attn_core_bwd16_kernel) ----
+            const bf16x8 qf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Qi + lp * AB_RS + q * 16));
+            const bf16x8 kf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Ki + lp * AB_RS + q * 16));
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Vi + lp * AB_RS + q * 16));
+            const bf16x8 df = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Di + lp * AB_RS + q * 16));
+            f32x4 ST = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf, z, 0, 0, 0);
+            f32x4 S = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, kf, z, 0, 0, 0);
+            f32x4 dPT = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, df, z, 0, 0, 0);
+            f32x4 dP = __builtin_amdgcn_mfma_f32_16x16x32_bf16(df, vf, z, 0, 0, 0);
+            f32x4 PT, dST;
+            {
+                float mx = -1e30f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { if (4 * q + e >= P.L) ST[e] = -1e30f; mx = fmaxf(mx, ST[e]); }
+                mx = max_q(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { PT[e] = __builtin_amdgcn_exp2f((ST[e] - mx) * SL2E); sum += PT[e]; }
+                const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
+                float dr = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { PT[e] *= inv; dr = fmaf(dPT[e], PT[e], dr); }
+                dr = reduce_q(dr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dST[e] = PT[e] * (dPT[e] - dr);
+            }
+            f32x4 Pn, dSn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float sv = (lp >= P.L) ? -1e30f : S[e];
+                const float mx = max16(sv);
+                const float pe = __builtin_amdgcn_exp2f((sv - mx) * SL2E);
+                const float pn = pe * __builtin_amdgcn_rcpf(reduce16(pe));
+                const float dr = reduce16(dP[e] * pn);
+                Pn[e] = pn; dSn[e] = pn * (dP[e] - dr);
+            }
+            const s16x4b bPT = pack4_bf16(PT), bdST = pack4_bf16(dST), bPn = pack4_bf16(Pn), bdSn = pack4_bf16(dSn);
+            uint2 pq[2], pk[2], pv[2];                                 // dq^T, dk^T, dv^T of this head, packed: rows d = 16 t + 4q + e, column = token lp
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const s16x4b av = tr_read4(Vi + troff + t * 32), ad = tr_read4(Di + troff + t * 32);
+                const s16x4b ak = tr_read4(Ki + troff + t * 32), aq = tr_read4(Qi + troff + t * 32);
+                const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(av, bPT, z, 0, 0, 0);
+                const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ad, bPn, z, 0, 0, 0);
+                const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ak, bdST, z, 0, 0, 0);
+                const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(aq, bdSn, z, 0, 0, 0);
+                const uint2 po = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+                pv[t] = make_uint2(pack_bf16x2(dv[0], dv[1]), pack_bf16x2(dv[2], dv[3]));
+                pq[t] = make_uint2(pack_bf16x2(dq[0] * P.scale, dq[1] * P.scale), pack_bf16x2(dq[2] * P.scale, dq[3] * P.scale));
+                pk[t] = make_uint2(pack_bf16x2(dk[0] * P.scale, dk[1] * P.scale), pack_bf16x2(dk[2] * P.scale, dk[3] * P.scale));
+                if (tvalid) {
+                    const int cc = h * 32 + t * 16 + 4 * q;
+                    *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.O) + (prow * 256 + cc) * 2) = po;
+                    char* dst = reinterpret_cast<char*>(P.dqkv) + (prow * 768 + cc) * 2;
+                    *reinterpret_cast<uint2*>(dst) = pq[t];
+                    *reinterpret_cast<uint2*>(dst + 512) = pk[t];
+                    *reinterpret_cast<uint2*>(dst + 1024) = pv[t];
+                }
+            }
+            // ---- dx^T += W_part,h^T d(part)^T: K slots (q, e) = d 4q + e (tile 0) | 16 + 4q + e (tile 1) on both operands ----
+#pragma unroll
+            for (int part = 0; part < 3; ++part) {
+                const uint2* pp = part == 0 ? pq : (part == 1 ? pk : pv);
+                const bf16x8 bfrag = __builtin_bit_cast(bf16x8, make_uint4(pp[0].x, pp[0].y, pp[1].x, pp[1].y));
+                const char* wb = Wi + (part * 256 + h * 32) * AX_RSW + trW;
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct) {
+                    const s16x4b lo = tr_read4(wb + ct * 32), hi = tr_read4(wb + 16 * AX_RSW + ct * 32);
+                    typedef short s16x8b __attribute__((ext_vector_type(8)));
+                    const s16x8b a8 = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    dxT[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a8), bfrag, dxT[ct], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // images are rewritten for the next head
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // ---- dx = g + ...: lane (token lp, q) owns channels 16 ct + 4q .. + 3 ----
+        if (tvalid) {
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct) {
+                const size_t o = prow * 64 + ct * 16 + 4 * q;
+                const float4 gg = *reinterpret_cast<const float4*>(P.g + o);
+                *reinterpret_cast<float4*>(P.dx + o) = make_float4(gg.x + dxT[ct][0], gg.y + dxT[ct][1], gg.z + dxT[ct][2], gg.w + dxT[ct][3]);
+            }
+        }
+    }
+}
+
+hipError_t launch_attn_bwd_fused(const AttnBwdXArgs& a, hipStream_t st) {
+    if (a.L < 1 || a.L > 16 || a.nseq < 1) return hipErrorInvalidValue;
+    const size_t lds = (size_t)768 * AX_RSW + 768 * 4 + (size_t)8 * 4 * 16 * AB_RS;
+    auto kfn = attn_bwd16x_kernel;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const long want = (a.nseq + 7) / 8;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)std::min<long>(want, cus)), dim3(512), lds, st, a);
+    return hipGetLastError();
+}
+
 constexpr int SLA_A = 2 * 1024 + 96;     // floats per (frame, head): ctx | dctx | kmax | ksum | T
 
 // pass A: one workgroup per (frame, head): softmax-over-pixels statistics of k, ctx = ksm^T v, dctx = qsm^T dOut, T = sum_e dctx*ctx

@@ -187,6 +187,19 @@ void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, 
     const long hw = (long)b.size(lvl) * b.size(lvl), Fr = m->cfg.num_frames;
     const int io16 = (m->mode == MODE_BF16 && (temporal ? Fr : hw) <= 16) ? 1 : 0;
     b.writes(b.S);                                                 // the scratch is rewritten from here on
+    if (m->mode == MODE_BF16 && temporal && C == 64 && H == 8 && Fr <= 16) {
+        // widest level: one fused kernel (attn_bwd16x_kernel) instead of recompute / dO projection / core / dx projection
+        AttnBwdXArgs f;
+        memset(&f, 0, sizeof(f));
+        f.x = x; f.g = g; f.wqkv = b.pk + ap.pk_qkv; f.bqkv = reinterpret_cast<const float*>(b.pk + ap.pk_bqkv); f.woT = b.pt + ap.pt_o;
+        f.O = O; f.dqkv = dq; f.dx = out; f.L = (int)Fr; f.nseq = b.B * hw; f.inner = hw; f.outer_p = Fr * hw; f.tok_p = hw;
+        f.scale = 1.0f / sqrtf((float)m->cfg.attn_dim_head);
+        b.writes(out);
+        b.ok(launch_attn_bwd_fused(f, b.st));
+        wgrad1x1(b, O, HD, g, C, ap.o_w, ap.o_b, lvl, 1);
+        wgrad1x1_qkv(b, x, C, dq, HD, ap.w, ap.b, lvl, 1);
+        return;
+    }
     proj(b, x, C, b.pk + ap.pk_qkv, reinterpret_cast<const float*>(b.pk + ap.pk_bqkv), 3 * HD, lvl, nullptr, qkv, 0, io16);
     proj(b, g, C, b.pt + ap.pt_o, nullptr, HD, lvl, nullptr, dO, 0, io16);                           // dO = g . Wo^T
     AttnBwdArgs a;

@@ -182,6 +182,17 @@ struct AttnBwdArgs {
     int bf16_mma;                                                    // bf16 MFMA form (bf16 mode, L <= 16) instead of the exact fp32 VALU form
 };
 hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st);
+// fused attention backward of the widest level (bf16 mode, C == 64, 8 heads x 32, <= 16 tokens): q/k/v recompute, dO = g Wo^T, the
+// core and dx = g + dq|dk|dv . Wqkv^T in one kernel; O and dq|dk|dv are written (bf16) for the weight-gradient kernels
+struct AttnBwdXArgs {
+    const float* x; const float* g;            // block input, dL/d(block output): fp32 [rows][64]
+    const void* wqkv; const float* bqkv;       // forward packing [3 * 256][64] bf16, biases [3 * 256]
+    const void* woT;                           // transposed packing of the out-projection [256][64] bf16
+    void* O; void* dqkv;                       // bf16 [rows][256], [rows][768]
+    float* dx;                                 // fp32 [rows][64]
+    int L; long nseq, inner, outer_p, tok_p; float scale;
+};
+hipError_t launch_attn_bwd_fused(const AttnBwdXArgs& a, hipStream_t st);
 // SLA core backward: q,k,v,dOut [NF*N][256] -> O (forward, pre to_out), dq, dk, dv ; A = scratch (sla_bwd_scratch_floats)
 struct SlaBwdArgs {
     const float* q; const float* k; const float* v; const float* dOut; float* O; float* dq; float* dk; float* dv; float* A;
