@@ -42,3 +42,17 @@ for t, d in ev:
     t_by_depth[depth] += (t - last) / 1e6; last = t; depth += d
 print('# time by number of kernels in flight (ms):', {k: round(v, 2) for k, v in sorted(t_by_depth.items())})
 print('# queues:', sorted({r['Queue_Id'] for r in rows}))
+# the longest idle gaps (nothing in flight) and the kernels either side
+ivs = sorted(((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].replace('vdx::', '').split('(')[0].replace('void ', '')[:40]) for r in rows))
+gaps = []
+cur_end, cur_name = ivs[0][1], ivs[0][2]
+for st, en, nm in ivs[1:]:
+    if st > cur_end:
+        gaps.append(((st - cur_end) / 1e3, cur_name, nm))
+    if en > cur_end:
+        cur_end, cur_name = en, nm
+gaps.sort(reverse=True)
+print(f'# {len(gaps)} idle gaps, total {sum(g[0] for g in gaps) / 1e3:.2f} ms; histogram (us):',
+      {b: sum(1 for g in gaps if lo <= g[0] < hi) for b, lo, hi in (('<2', 0, 2), ('2-5', 2, 5), ('5-10', 5, 10), ('10-20', 10, 20), ('>20', 20, 1e9))})
+for g in gaps[:12]:
+    print(f'  {g[0]:7.1f} us  after {g[1]:40s} before {g[2]}')

@@ -37,24 +37,35 @@ struct Bwd {
     // stream before it overwrites a buffer a pending side kernel reads (writes()), and at the end of every stage (join()): a
     // stage's parameter gradients are final when the stage returns, as the data-parallel reducer assumes.
     BwdState* state = nullptr;
-    std::vector<const void*> pending;               // buffers read by side kernels the main stream has not waited for
-    bool main_dirty = true;
+    struct Pending { const void* buf; hipEvent_t done; int seq; };
+    std::vector<Pending> pending;                   // buffers read by side kernels the main stream has not waited for
+    bool main_dirty = true; int seq = 0;
     hipEvent_t next_event() { hipEvent_t e = state->ev[state->ev_next]; state->ev_next = (state->ev_next + 1) % BWD_EVENTS; return e; }
-    hipStream_t side(const void* r0, const void* r1 = nullptr) {
+    // the stream of a leaf kernel; side_done() after its launch names the buffers it reads
+    hipStream_t side() {
         if (!state->side) return st;
+        if ((int)pending.size() > BWD_EVENTS / 4) join();           // (an event of the ring is never reused while an entry still names it)
         if (main_dirty) { hipEvent_t e = next_event(); ok(hipEventRecord(e, st)); ok(hipStreamWaitEvent(state->side, e, 0)); main_dirty = false; }
-        if (r0) pending.push_back(r0);
-        if (r1) pending.push_back(r1);
         return state->side;
     }
-    void join() {
-        if (pending.empty()) return;
-        hipEvent_t e = next_event(); ok(hipEventRecord(e, state->side)); ok(hipStreamWaitEvent(st, e, 0));
-        pending.clear();
+    void side_done(const void* r0, const void* r1 = nullptr) {
+        if (!state->side) return;
+        hipEvent_t e = next_event(); ok(hipEventRecord(e, state->side)); ++seq;
+        if (r0) pending.push_back({r0, e, seq});
+        if (r1) pending.push_back({r1, e, seq});
     }
+    void wait_side(int upto, hipEvent_t e) {                         // the side stream runs in order: waiting for one kernel covers the earlier ones
+        ok(hipStreamWaitEvent(st, e, 0));
+        size_t k = 0;
+        for (const Pending& p : pending) if (p.seq > upto) pending[k++] = p;
+        pending.resize(k);
+    }
+    void join() { if (!pending.empty()) wait_side(pending.back().seq, pending.back().done); }
     // the main stream is about to launch a kernel that writes w0 / w1
     hipStream_t writes(const void* w0, const void* w1 = nullptr) {
-        for (const void* p : pending) if (p == w0 || (w1 && p == w1)) { join(); break; }
+        const Pending* last = nullptr;
+        for (const Pending& p : pending) if (p.buf == w0 || (w1 && p.buf == w1)) last = &p;
+        if (last) wait_side(last->seq, last->done);
         main_dirty = true;
         return st;
     }
@@ -70,10 +81,10 @@ size_t lvl_width(const Model* m, int l) {
 
 // data gradient through a conv: out[.., cin_rows] = conv(dy; transposed packing rows [row0, row0+nrows)) (+ res)
 void dgrad(Bwd& b, const float* dy, int Cdy, const void* wpt, int rows_total, int row0, int nrows, int lvl_in, int kind_fwd, int k,
-           int stride_fwd, const float* res, float* out) {
+           int stride_fwd, const float* res, float* out, int dy_bf16 = 0) {
     ConvArgs a;
     memset(&a, 0, sizeof(a));
-    a.x0 = dy; a.C0 = Cdy; a.wp = wpt; a.y = out; a.Cout = nrows; a.wrows = rows_total; a.wrow0 = row0; a.res = res;
+    a.x0 = dy; a.C0 = Cdy; a.x0_bf16 = dy_bf16; a.wp = wpt; a.y = out; a.Cout = nrows; a.wrows = rows_total; a.wrow0 = row0; a.res = res;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames;
     // lvl_in = level of the FORWARD conv's input; dy lives at the forward output resolution
     if (kind_fwd == 0 && stride_fwd == 1) { a.H = a.W = b.size(lvl_in); a.kind = 0; a.kh = a.kw = k; a.stride = 1; a.pad = (k - 1) / 2; }
@@ -83,15 +94,18 @@ void dgrad(Bwd& b, const float* dy, int Cdy, const void* wpt, int rows_total, in
 }
 
 void wgrad(Bwd& b, const float* x0, int c0, const float* x1, int c1, const float* dy, int Cout, long w_off, long b_off, int lvl_in, int kind, int k, int stride,
-           const double* in_stats = nullptr, const float* gamma = nullptr, const float* beta = nullptr, const float* ss = nullptr, int ss_stride = 0) {
+           const double* in_stats = nullptr, const float* gamma = nullptr, const float* beta = nullptr, const float* ss = nullptr, int ss_stride = 0,
+           int dy_bf16 = 0) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
+    a.dy_bf16 = dy_bf16;
     a.x0 = x0; a.x1 = x1; a.C0 = c0; a.C1 = c1; a.dy = dy; a.Cout = Cout; a.dW = b.grads + w_off; a.db = b_off >= 0 ? b.grads + b_off : nullptr;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl_in);
     a.kind = kind; a.kh = a.kw = kind ? 4 : k; a.stride = kind ? 1 : stride;
     a.bf16_mma = (b.m->mode == MODE_BF16);
     if (in_stats) { a.x0_bf16 = (b.m->mode == MODE_BF16); a.pro = 1; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta; a.groups = b.m->cfg.resnet_groups; a.ss = ss; a.ss_stride = ss_stride; }
-    b.ok(launch_conv_wgrad(a, b.side(dy)));
+    b.ok(launch_conv_wgrad(a, b.side()));
+    b.side_done(dy);
 }
 
 
@@ -105,7 +119,8 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     // 1. tail: out = SiLU(GN2(y2)) + LN(r)
     NormBwdArgs t;
     memset(&t, 0, sizeof(t));
-    t.dact = g; t.y = b.slot(r.s_y2); t.y_bf16 = (m->mode == MODE_BF16); t.dy = L.t1; t.stats = b.stat(r.st2); t.gamma = b.p + r.b2_gs; t.beta = b.p + r.b2_gb; t.groups = G;
+    const int d16 = (m->mode == MODE_BF16) ? 1 : 0;      // bf16 mode: dL/d(y2), dL/d(y1) are bf16 tensors (only convolutions read them)
+    t.dact = g; t.y = b.slot(r.s_y2); t.y_bf16 = (m->mode == MODE_BF16); t.dy = L.t1; t.dy_bf16 = d16; t.stats = b.stat(r.st2); t.gamma = b.p + r.b2_gs; t.beta = b.p + r.b2_gb; t.groups = G;
     t.d_gamma = b.grads + r.b2_gs; t.d_beta = b.grads + r.b2_gb;
     t.r = rsrc; t.ln_gamma = b.p + r.n2_s; t.dr = L.t2; t.d_ln_gamma = b.grads + r.n2_s; t.d_ln_beta = b.grads + r.n2_b;
     // R at a fixed offset of the scratch: zeroed once per backward, the finalize pass leaves it zero again
@@ -113,29 +128,29 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     b.ok(launch_norm_bwd(t, b.writes(L.t1, L.t2)));
     // 2. conv2: y2 = conv(SiLU(GN1(y1)*(1+s)+sh)); the weight gradients that only need the tail's outputs go to the side stream now
     const float* ssrow = r.has_mlp ? b.ss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
-    wgrad(b, b.slot(r.s_y1), r.cout, nullptr, 0, L.t1, r.cout, r.b2_w, r.b2_b, lvl, 0, 3, 1, b.stat(r.st1), b.p + r.b1_gs, b.p + r.b1_gb, ssrow, 2 * r.cout);
+    wgrad(b, b.slot(r.s_y1), r.cout, nullptr, 0, L.t1, r.cout, r.b2_w, r.b2_b, lvl, 0, 3, 1, b.stat(r.st1), b.p + r.b1_gs, b.p + r.b1_gb, ssrow, 2 * r.cout, d16);
     if (r.has_res) wgrad(b, x0, c0, x1, c1, L.t2, r.cout, r.rc_w, r.rc_b, lvl, 0, 1, 1);
-    dgrad(b, L.t1, r.cout, b.pt + r.pt_b2, r.cout, 0, r.cout, lvl, 0, 3, 1, nullptr, L.t3);            // dL/d(act1)
+    dgrad(b, L.t1, r.cout, b.pt + r.pt_b2, r.cout, 0, r.cout, lvl, 0, 3, 1, nullptr, L.t3, d16);       // dL/d(act1)
     // 3. prologue: act1 = SiLU((GN1(y1))*(1+s)+sh)
     NormBwdArgs q;
     memset(&q, 0, sizeof(q));
-    q.dact = L.t3; q.y = b.slot(r.s_y1); q.y_bf16 = (m->mode == MODE_BF16); q.dy = L.t4; q.stats = b.stat(r.st1); q.gamma = b.p + r.b1_gs; q.beta = b.p + r.b1_gb; q.groups = G;
+    q.dact = L.t3; q.y = b.slot(r.s_y1); q.y_bf16 = (m->mode == MODE_BF16); q.dy = L.t4; q.dy_bf16 = d16; q.stats = b.stat(r.st1); q.gamma = b.p + r.b1_gs; q.beta = b.p + r.b1_gb; q.groups = G;
     q.ss = ssrow; q.ss_stride = 2 * r.cout; q.d_gamma = b.grads + r.b1_gs; q.d_beta = b.grads + r.b1_gb;
     q.dss = r.has_mlp ? b.dss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
     q.G = b.normscr; q.R = b.normscr + (size_t)b.B * 64; q.r_clean = 1; q.C = r.cout; q.batch = b.B; q.pix_per_sample = b.pix(lvl);
     b.ok(launch_norm_bwd(q, b.writes(L.t4)));                                                           // t4 = dL/d(y1) (not t1: conv2's weight gradient may still be reading it)
     // 4. conv1 + residual branch
-    wgrad(b, x0, c0, x1, c1, L.t4, r.cout, r.b1_w, r.b1_b, lvl, 0, 3, 1);
+    wgrad(b, x0, c0, x1, c1, L.t4, r.cout, r.b1_w, r.b1_b, lvl, 0, 3, 1, nullptr, nullptr, nullptr, nullptr, 0, d16);
     const int cin = c0 + c1;
     if (r.has_res) {
         dgrad(b, L.t2, r.cout, b.pt + r.pt_rc, cin, 0, c0, lvl, 0, 1, 1, nullptr, L.t3);
-        dgrad(b, L.t4, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t3, out0);
+        dgrad(b, L.t4, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t3, out0, d16);
         if (c1) {
             dgrad(b, L.t2, r.cout, b.pt + r.pt_rc, cin, c0, c1, lvl, 0, 1, 1, nullptr, L.t3);
-            dgrad(b, L.t4, r.cout, b.pt + r.pt_b1, cin, c0, c1, lvl, 0, 3, 1, L.t3, out1);
+            dgrad(b, L.t4, r.cout, b.pt + r.pt_b1, cin, c0, c1, lvl, 0, 3, 1, L.t3, out1, d16);
         }
     } else {
-        dgrad(b, L.t4, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t2, out0);                   // identity residual: + dL/d(r)
+        dgrad(b, L.t4, r.cout, b.pt + r.pt_b1, cin, 0, c0, lvl, 0, 3, 1, L.t2, out0, d16);              // identity residual: + dL/d(r)
     }
 }
 
@@ -159,7 +174,8 @@ void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
     a.bf16_mma = (b.m->mode == MODE_BF16);
-    b.ok(launch_conv_wgrad(a, b.side(b.S, dy)));                   // x = O lives in the attention scratch
+    b.ok(launch_conv_wgrad(a, b.side()));
+    b.side_done(b.S, dy);                                          // x = O lives in the attention scratch
 }
 
 // the q, k and v projection weight gradients of one block in ONE launch: dy = [rows][dq | dk | dv], x read once
@@ -173,7 +189,8 @@ void wgrad1x1_qkv(Bwd& b, const float* x, int cin, const float* dqkv, int hd, co
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
     a.bf16_mma = (b.m->mode == MODE_BF16);
-    b.ok(launch_conv_wgrad(a, b.side(b.S)));                       // dq | dk | dv live in the attention scratch
+    b.ok(launch_conv_wgrad(a, b.side()));
+    b.side_done(b.S);                                              // dq | dk | dv live in the attention scratch
 }
 
 // y = MHA(x) + x  backward: g = dL/dy -> out = dL/dx
@@ -406,7 +423,8 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             float* o = other(LB, g);
             attn_bwd(b, m->init_attn, g, b.slot(m->s_init), 0, true, o); g = o;
             VDX_E(launch_init_conv_wgrad(x, g, grads + m->init_w, grads + m->init_b, B, c.channels, c.num_frames, c.image_size, c.image_size,
-                                         m->init_dim, c.init_kernel_size, b.side(g)));
+                                         m->init_dim, c.init_kernel_size, b.side()));
+            b.side_done(g);
             TimeMlpArgs t;
             memset(&t, 0, sizeof(t));
             t.time = time; t.w1 = params + m->t_w1; t.b1 = params + m->t_b1; t.w2 = params + m->t_w2; t.b2 = params + m->t_b2;

@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs P) {
                     const float xh = (yv[e] - mu[c + e]) * rsd[c + e];
                     o[e] = ta[c + e] * dz - rsd[c + e] * (gs[2 * g] + xh * gs[2 * g + 1]);     // ta = rstd * gamma * (1+s)
                 }
-                *reinterpret_cast<float4*>(P.dy + base + c) = make_float4(o[0], o[1], o[2], o[3]);
+                store4_f32_or_bf16(P.dy, base + c, make_float4(o[0], o[1], o[2], o[3]), P.dy_bf16);
                 if (P.r) {
                     const float4 lg = *reinterpret_cast<const float4*>(P.ln_gamma + c);
                     const float lgv[4] = {lg.x, lg.y, lg.z, lg.w}, rv[4] = {rr[v].x, rr[v].y, rr[v].z, rr[v].w};

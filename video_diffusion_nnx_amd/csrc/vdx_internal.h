@@ -161,6 +161,7 @@ hipError_t launch_add_inplace(float* y, const float* x, long n, hipStream_t st);
 struct NormBwdArgs {
     const float* dact; const float* y; float* dy;                 // dL/dact (or dL/dout), saved pre-norm tensor, result dL/dy
     int y_bf16;                                                   // y stored as bf16
+    int dy_bf16;                                                  // dy written as bf16 (its consumers, the conv data / weight gradients, round it to bf16 anyway)
     const double* stats; const float* gamma; const float* beta; int groups;
     const float* ss; int ss_stride;                               // forward scale/shift rows or null
     float* d_gamma; float* d_beta;                                // accumulated (atomics)
