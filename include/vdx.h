@@ -289,6 +289,15 @@ int vdx_attention_core_backward(const float* qkv, const float* d_o, float* o, fl
 int vdx_attention_core_backward_ex(const float* qkv, const float* d_o, float* o, float* dq, float* dk, float* dv, int batch, int frames,
                                    int h, int w, int heads, int temporal, int bf16_operands, void* stream);
 
+/* Whole backward of a temporal attention block y = MHA(x) + x (modules.py:271-327 under Residual, unet3d.py:284,308,365) except its
+ * weight gradients, in one pass over x and dy: the shape a VDX_MODE_BF16 handle's backward runs at the widest level (C = 64 channels,
+ * 8 heads x 32, sequences over <= 16 frames per (b, h, w); bf16 operands, fp32 accumulate).  x, dy, dx: fp32 [B][F][h][w][64];
+ * packed_wqkv = vdx_pack_conv_weights(BF16) of the [64][q|k|v = 768] kernel, bqkv [768]; packed_wo_t =
+ * vdx_pack_conv_weights_t(BF16) of the [256][64] out kernel.  Writes dx = dy + d(q|k|v) Wqkv^T and, as bf16 tensors for the
+ * weight-gradient kernels, o [rows][256] (attention output before the out projection) and dqkv [rows][768]. */
+int vdx_temporal_attention_backward_fused(const float* x, const float* dy, const void* packed_wqkv, const float* bqkv, const void* packed_wo_t,
+                                          void* o_bf16, void* dqkv_bf16, float* dx, int batch, int frames, int h, int w, void* stream);
+
 /* SpatialLinearAttention core backward (autodiff of modules.py:105-118 per frame and head; heads = 8, D = 32).
  * q, k, v, d_out [B*F*h*w][256]; writes o (pre to_out), dq, dk, dv.  scratch >= vdx_sla_backward_scratch_floats floats. */
 size_t vdx_sla_backward_scratch_floats(int nframes, int heads);

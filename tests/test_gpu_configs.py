@@ -96,6 +96,39 @@ def test_unet_backward_north_star_shape(n_shape_reference, mode, tol):
     assert total < tol, total
 
 
+# The fused temporal-attention backward of the widest level (attn_bwd16x_kernel: bf16 mode, C = 64, 8 heads) with sequences
+# shorter than its 16-token tile (masked keys, zero rows) and B = 2: gradients of the three level-0 attention blocks and the whole
+# network against fp64 autograd through the oracle.
+def test_fused_temporal_attention_backward_short_sequences():
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    kw = dict(dim=64, channels=1, dim_mults=(1, 2))
+    cfg = R.UnetConfig(**kw)
+    p64 = R.random_params(cfg, seed=23, dtype=torch.float64)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 1, 6, 16, 16, generator=g)
+    t = torch.tensor([3, 911])
+    d_out = torch.randn(2, 6, 16, 16, 1, generator=g)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p64.items()}
+    out = R.unet_forward(leaves, cfg, x.double(), t)
+    ref = torch.autograd.grad(out, list(leaves.values()), d_out.double(), allow_unused=True)
+    ref_grads = {k: (torch.zeros_like(v) if gr is None else gr.detach()) for (k, v), gr in zip(leaves.items(), ref)}
+    m = Unet3D(rngs=0, mode='bf16', **kw)
+    m.load_state_dict({k: v.float() for k, v in p64.items()})
+    m(x, t)
+    grads = torch.zeros_like(m.flat_params)
+    m.backward(d_out.to(m.device), grads)
+    torch.cuda.synchronize()
+    rows = _per_tensor(m, grads, ref_grads)
+    scale = _flat(m, ref_grads).norm().item()
+    total = _rel(_got_flat(m, grads), _flat(m, ref_grads))
+    attn = [(n, r) for n, r, nr, _ in rows if nr > 1e-6 * scale and ('init_temporal_attn' in n or n.startswith('downs.0.3') or n.startswith('ups.1.3'))
+            and '.fn.norm.' not in n]
+    assert len(attn) >= 3 * 7, [n for n, _ in attn]      # (k biases have zero gradient: softmax is shift-invariant)
+    print(f'short-sequence fused attention backward: total {total:.3e}; level-0 attention tensors worst {sorted(attn, key=lambda z: -z[1])[:4]}')
+    assert max(r for _, r in attn) < 8e-2, sorted(attn, key=lambda z: -z[1])[:4]
+    assert total < 2.5e-2, total
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # (b) the benchmarked batch
 # ------------------------------------------------------------------------------------------------------------------

@@ -185,6 +185,38 @@ def test_attention_core_backward(B, Fr, H, W, heads, temporal):
     assert _rel(torch.cat([dq, dk, dv], -1).cpu().double(), gqkv) < tol
 
 
+# y = MHA(x) + x over the frames of every pixel (modules.py:271-327 under Residual); the fused kernel returns dx and the two tensors
+# the weight-gradient kernels read (o = attention output before the out projection, d(q|k|v)).  bf16 operands: 1.5e-2 (as the unfused
+# bf16 core above); 16 frames = full tiles, 5 frames = masked keys / zero rows, odd pixel counts = ragged last workgroup.
+@pytest.mark.parametrize('B,Fr,H,W', [(1, 16, 4, 4), (2, 5, 3, 3), (1, 16, 16, 16)])
+def test_temporal_attention_backward_fused(B, Fr, H, W):
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(100 + B + Fr + H)
+    D = torch.float64
+    x = torch.randn(B, Fr, H, W, 64, generator=g, dtype=D).requires_grad_(True)
+    dy = torch.randn(B, Fr, H, W, 64, generator=g, dtype=D)
+    wqkv = (torch.randn(64, 768, generator=g, dtype=D) * 0.15).requires_grad_(True)
+    bqkv = (torch.randn(768, generator=g, dtype=D) * 0.1).requires_grad_(True)
+    wo = (torch.randn(256, 64, generator=g, dtype=D) * 0.1).requires_grad_(True)
+    rows = x.reshape(-1, 64)
+    qkv = rows @ wqkv + bqkv                                       # [rows][q | k | v], head-major inside each third
+    s = qkv.reshape(B, Fr, H * W, 3, 8, 32).permute(0, 2, 1, 3, 4, 5)       # b (hw) f part head d
+    q, k, v = s[..., 0, :, :] / 32 ** 0.5, s[..., 1, :, :], s[..., 2, :, :]
+    att = torch.softmax(torch.einsum('...ihd,...jhd->...hij', q, k), -1)
+    o = torch.einsum('...hij,...jhd->...ihd', att, v).permute(0, 2, 1, 3, 4).reshape(-1, 256)
+    y = (o @ wo).reshape(x.shape) + x
+    o.retain_grad(); qkv.retain_grad()
+    y.backward(dy)
+    dx, og, dqkv = ops.temporal_attention_backward_fused(x.detach().float().to(DEV), dy.float().to(DEV), wqkv.detach().float().to(DEV),
+                                                         bqkv.detach().float().to(DEV), wo.detach().float().to(DEV))
+    torch.cuda.synchronize()
+    assert _rel(og.float().cpu().double(), o.detach()) < 1.5e-2
+    assert _rel(dqkv.float().cpu().double(), qkv.grad) < 1.5e-2, _rel(dqkv.float().cpu().double(), qkv.grad)
+    assert _rel(dx.cpu().double(), x.grad) < 1.5e-2, _rel(dx.cpu().double(), x.grad)
+    # the attention branch alone (dx - dy), so that the residual does not mask an error
+    assert _rel(dx.cpu().double() - dy, x.grad - dy) < 2.5e-2
+
+
 @pytest.mark.parametrize('NF,H,W', [(2, 8, 8), (3, 5, 7), (1, 20, 20)])
 def test_sla_core_backward(NF, H, W):
     from video_diffusion_nnx_amd import ops

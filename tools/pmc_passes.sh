@@ -33,7 +33,7 @@ for f in root.rglob('*counter_collection.csv'):
         k = r['Kernel_Name'].split('(')[0][-60:]
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in acc.items():
-    if 'conv' not in k and 'attention' not in k and 'sla' not in k and 'tail' not in k: continue
+    if not any(t in k for t in ('conv', 'attention', 'sla', 'tail', 'attn', 'wgrad', 'norm')): continue
     print('==', k)
     for c, v in sorted(d.items()):
         print(f'   {c:40s} n={len(v):3d} avg={sum(v)/len(v):16.1f}')

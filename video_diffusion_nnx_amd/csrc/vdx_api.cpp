@@ -483,6 +483,19 @@ int vdx_attention_core_backward_ex(const float* qkv, const float* d_o, float* o,
     return VDX_OK;
 }
 
+int vdx_temporal_attention_backward_fused(const float* x, const float* dy, const void* packed_wqkv, const float* bqkv, const void* packed_wo_t,
+                                          void* o_bf16, void* dqkv_bf16, float* dx, int batch, int frames, int h, int w, void* stream) {
+    if (!x || !dy || !packed_wqkv || !bqkv || !packed_wo_t || !o_bf16 || !dqkv_bf16 || !dx) VDX_FAIL(VDX_ERR_INVALID, "temporal_attention_backward_fused: null argument");
+    if (batch < 1 || frames < 1 || frames > 16 || h < 1 || w < 1) VDX_FAIL(VDX_ERR_INVALID, "temporal_attention_backward_fused: 1..16 frames");
+    vdx::AttnBwdXArgs a;
+    memset(&a, 0, sizeof(a));
+    const long hw = (long)h * w;
+    a.x = x; a.g = dy; a.wqkv = packed_wqkv; a.bqkv = bqkv; a.woT = packed_wo_t; a.O = o_bf16; a.dqkv = dqkv_bf16; a.dx = dx;
+    a.L = frames; a.nseq = (long)batch * hw; a.inner = hw; a.outer_p = (long)frames * hw; a.tok_p = hw; a.scale = 1.0f / sqrtf(32.0f);
+    VDX_HIP(vdx::launch_attn_bwd_fused(a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
 size_t vdx_sla_backward_scratch_floats(int nframes, int heads) { return vdx::sla_bwd_scratch_floats(nframes, heads); }
 
 int vdx_sla_core_backward(const float* q, const float* k, const float* v, const float* d_out, float* o, float* dq, float* dk, float* dv,

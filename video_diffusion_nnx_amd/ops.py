@@ -213,6 +213,25 @@ def attention_core_backward(qkv, d_o, B, Fr, H, W, heads, temporal, bf16_operand
     return outs      # o, dq, dk, dv
 
 
+_attn_bwd_fused = L._sig('vdx_temporal_attention_backward_fused', C.c_int, [C.c_void_p] * 8 + [C.c_int] * 4 + [C.c_void_p])
+
+
+def temporal_attention_backward_fused(x, dy, wqkv, bqkv, wo):
+    """x, dy: fp32 (B, F, H, W, 64); wqkv (64, 768) = [Wq | Wk | Wv], bqkv (768,), wo (256, 64) Flax kernels.
+    Returns dx (fp32), o (rows, 256) and dqkv (rows, 768) as bfloat16 (the bf16-mode backward of the widest level's temporal attention)."""
+    B, Fr, H, W, C_ = x.shape
+    assert C_ == 64 and wqkv.shape == (64, 768) and wo.shape == (256, 64)
+    pw = pack_conv_weights(wqkv, 'bf16')
+    pwo_t = pack_conv_weights_t(wo, 'bf16')
+    rows = B * Fr * H * W
+    o = torch.empty(rows, 256, dtype=torch.bfloat16, device=x.device)
+    dqkv = torch.empty(rows, 768, dtype=torch.bfloat16, device=x.device)
+    dx = torch.empty_like(x)
+    bq = bqkv.contiguous().float()
+    L.check(_attn_bwd_fused(L.ptr(x), L.ptr(dy), L.ptr(pw), L.ptr(bq), L.ptr(pwo_t), L.ptr(o), L.ptr(dqkv), L.ptr(dx), B, Fr, H, W, L.stream_ptr()))
+    return dx, o, dqkv
+
+
 def sla_core_backward(q, k, v, d_out, nframes, npix, heads=8, bf16_operands=False):
     outs = [torch.empty_like(q) for _ in range(4)]
     scr = torch.empty(_sla_scr(nframes, heads), dtype=torch.float32, device=q.device)
