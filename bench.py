@@ -74,67 +74,85 @@ def conv_bytes(layer, frames, batch, mode, act='f32'):
     return ea * batch * frames * (s * s * cin + so * so * cout) + es * taps * cin * cout
 
 
-def time_conv_kernels(unet, frames, size, batch, mode, act='f32', reps=5):
-    """Roofline leg: replays every conv_igemm launch shape of one forward standalone (tensors in the storage type the timed
-    region used), HIP events on the launch stream."""
+def conv_symbol(i):
+    """rocprofv3's name of the kernel a vdx_conv_launch_info describes (template arguments as the profiler prints them)."""
+    tf = lambda v: 'true' if v else 'false'
+    if i.kernel == 1:
+        return f'vdx::conv64p_kernel<{tf(i.x_bf16)}, {tf(i.pro)}, {tf(i.y_bf16)}>'
+    if i.kernel == 2:
+        return 'vdx::conv128x64p_kernel'
+    if i.kernel == 3:
+        return f'vdx::conv3x3_ws_kernel<{i.geo}, {tf(i.pro)}>'
+    return f'vdx::conv_igemm_kernel<{i.mode}, {i.bc}, 2, {i.nw}, {i.inf}>'
+
+
+def conv_info_work(i, mode):
+    """(FLOPs, algorithmic HBM bytes) of one conv launch: input + output tensors in their storage type + packed weights
+    (SURVEY 8d op-level definition; ConvTranspose = 4 effective taps per output pixel)."""
+    es = 2.0 if mode == 'bf16' else 4.0
+    ein, eout = (2.0 if i.x_bf16 else 4.0), (2.0 if i.y_bf16 else 4.0)
+    if i.kind == 1:
+        ho, wo, eff = 2 * i.h, 2 * i.w, 4
+    else:
+        ho, wo, eff = -(-i.h // i.stride), -(-i.w // i.stride), i.taps
+    flops = 2.0 * i.nf * ho * wo * i.cin * i.cout * eff
+    nbytes = ein * i.nf * i.h * i.w * i.cin + eout * i.nf * ho * wo * i.cout + es * i.taps * i.cin * i.cout
+    return flops, nbytes
+
+
+def time_convs_in_step(run_eager, dev, mode, steps=3):
+    """Roofline leg: HIP-event duration of every convolution launch INSIDE the real denoising step.  The library calls a hook
+    before / after each conv launch (vdx_set_conv_launch_hook, include/vdx.h); the hook records a torch event on the launch
+    stream, so each launch of `steps` eager (not graph-replayed) steps of the timed region's own loop is bracketed by its own pair.
+    Why not a stand-alone replay: back-to-back repetitions of one MFMA + HBM-heavy shape on random data run 25-80 % above the
+    same kernel's duration inside the step (rocprofv3 traces of both; the level-0 conv: 265 us in the step, 330-500 us replayed,
+    350 us on all-zero data) -- sustained identical launches pull the clocks down in a way the step's kernel mix does not."""
+    import ctypes as C
     import torch
-    from video_diffusion_nnx_amd import ops
-    dev = unet.device
-    per_symbol = {}
+    from video_diffusion_nnx_amd import _lib as L
+
+    class Info(C.Structure):
+        _fields_ = [(n, C.c_int) for n in ('kernel', 'mode', 'bc', 'nw', 'inf', 'geo', 'pro', 'x_bf16', 'y_bf16',
+                                           'cin', 'cout', 'h', 'w', 'nf', 'taps', 'kind', 'stride')]
+    HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(Info), C.c_void_p)
+    set_hook = L._sig('vdx_set_conv_launch_hook', None, [HOOK, C.c_void_p])
     st = torch.cuda.current_stream(dev)
-    for layer in conv_layers(unet.dim, unet.dim_mults, frames, size, batch):
-        cin, cout, s, taps, kind = layer
-        k = {9: 3, 1: 1, 16: 4}[taps]
-        x = torch.randn(batch, frames, s, s, cin, device=dev)
-        if act == 'bf16':
-            x = x.to(torch.bfloat16)
-        w = torch.randn(1, k, k, cin, cout, device=dev) / (taps * cin) ** 0.5
-        pw = ops.pack_conv_weights(w, mode)
-        bias = torch.zeros(cout, device=dev)
-        stats_in = ops.gn_stats_zeros(batch, 8, dev)
-        stats_in.view(batch, 32, 8, 2)[:, 0, :, 1] = float(frames * s * s * cin // 8)     # unit variance statistics
-        stats_out = ops.gn_stats_zeros(batch, 8, dev)
-        gamma = torch.ones(cin, device=dev); beta = torch.zeros(cin, device=dev)
-        kwargs = dict(mode=mode, bias=bias, y_bf16=(act == 'bf16'))
-        if kind == 'c3':
-            kwargs.update(k=3, out_stats=stats_out)
-        elif kind == 'c3p':
-            kwargs.update(k=3, in_stats=stats_in, gamma=gamma, beta=beta, out_stats=stats_out)
-        elif kind == 'c1':
-            kwargs.update(k=1)
-        elif kind == 'down':
-            kwargs.update(k=4, stride=2)
+    records, open_ev = [], []
+
+    def hook(user, phase, info, stream):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(st)
+        if phase == 0:
+            open_ev.append(e)
         else:
-            kwargs.update(k=4, kind=1)
-        ops.conv_forward(x, pw, cout, **kwargs)                                          # warm-up
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        for _ in range(reps):
-            ops.conv_forward(x, pw, cout, **kwargs)
-        e1.record(st)
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        mode_id = {'f32': 0, 'bf16': 1}[mode]                                              # rocprof prints the template arguments
-        narrow = cout <= 64 and kind == 'down'                                           # launch_conv: TN = 2 / 4 waves; else 8 waves x TN 2
-        inf = 0 if act != 'bf16' else (2 if cin % 8 == 0 else 1)                        # launch_conv: input storage variant (fp32 / bf16 / 16-byte bf16)
-        sym = f'vdx::conv_igemm_kernel<{mode_id}, {64 if cout <= 64 else 128}, 2, {4 if narrow else 8}, {inf}>'
-        if (mode == 'bf16' and kind in ('c3', 'c3p') and cin == 64 and cout == 64 and s % 16 == 0
-                and batch * frames * (s // 16) ** 2 >= 1024):                            # launch_conv's persistent level-0 specialisation
-            b16 = 'true' if act == 'bf16' else 'false'                                    # template <IN16, PRO, OUT16>
-            sym = f'vdx::conv64p_kernel<{b16}, {"true" if kind == "c3p" else "false"}, {b16}>'
-        if (mode == 'bf16' and act == 'bf16' and kind == 'c3' and cin == 128 and cout == 64 and s % 16 == 0
-                and batch * frames * (s // 16) ** 2 >= 1024):
-            sym = 'vdx::conv128x64p_kernel'
-        if mode == 'bf16' and act == 'bf16' and kind in ('c3', 'c3p') and cout % 128 == 0 and cin % 64 == 0 and (s % 16 == 0 or s == 8):
-            tiles = batch * frames * (s // 16) ** 2 if s % 16 == 0 else batch * frames // 4
-            if tiles * (cout // 128) >= 128 and cout // 128 in (1, 2, 4, 8):               # conv3x3_ws_eligible (conv_ws.hip)
-                geo = 8 if s == 8 else (16 if s == 16 else 0)                            # conv_ws.hip ws_geo(): whole frames / 16 x 16 tiles
-                sym = f'vdx::conv3x3_ws_kernel<{geo}, {"true" if kind == "c3p" else "false"}>'
-        launches = 4 if kind == 'up' else 1                                              # the 4 phases are one launch (grid.z)
-        d = per_symbol.setdefault(sym, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-        d['ms'] += ms; d['flops'] += conv_flops(layer, frames, batch); d['bytes'] += conv_bytes(layer, frames, batch, mode, act); d['launches'] += 1
-        del x, w, pw
-    return per_symbol
+            i = info.contents
+            snap = Info(*[getattr(i, n) for n, _ in Info._fields_])
+            records.append((snap, open_ev.pop(), e))
+    cb = HOOK(hook)
+    run_eager(1)                                       # eager path warm-up (first-call attributes), not recorded
+    torch.cuda.synchronize(dev)
+    # what an event pair with NOTHING between its records reads on this stream (the two marker packets themselves): subtracted
+    pairs = []
+    for _ in range(32):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(st); b.record(st)
+        pairs.append((a, b))
+    torch.cuda.synchronize(dev)
+    overhead_ms = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
+    set_hook(cb, None)
+    try:
+        run_eager(steps)
+        torch.cuda.synchronize(dev)
+    finally:
+        set_hook(C.cast(None, HOOK), None)
+    per_symbol = {}
+    for info, e0, e1 in records:
+        fl, by = conv_info_work(info, mode)
+        d = per_symbol.setdefault(conv_symbol(info), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        d['ms'] += max(e0.elapsed_time(e1) - overhead_ms, 0.0) / steps; d['flops'] += fl / steps; d['bytes'] += by / steps; d['launches'] += 1
+    for d in per_symbol.values():
+        d['launches'] = d['launches'] // steps
+    return per_symbol, overhead_ms * 1e3
 
 
 def cpu_baseline(dim, frames, size, budget_s=20.0):
@@ -316,6 +334,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
+        per = None
+        if rank == 0 and not args.no_roofline:
+            def run_eager(n):
+                L.check(vdx_p_sample_loop(h.ptr, L.ptr(unet.flat_params), L.ptr(packed), L.ptr(img), L.ptr(eps), L.ptr(t_dev), L.ptr(step_dev),
+                                          L.ptr(gd._ptab), T_STEPS, n, 0, 1000 + rank, 1, L.ptr(ws), ws.numel(), B, 0, L.stream_ptr()))
+            log('roofline leg: events around every conv launch of 3 eager steps of the same loop ...')
+            per, ev_overhead_us = time_convs_in_step(run_eager, dev, args.mode)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -343,9 +368,6 @@ def main():
         line['train'] = train_leg(args, dev, world, rank)         # every rank takes part (collectives inside)
         log(f"training leg done: {line['train']['ms_per_step']:.2f} ms/step, {line['train']['samples_per_s']:.1f} samples/s")
     if rank == 0 and not args.no_roofline:
-        log('roofline leg: replaying conv launch shapes ...')
-        with torch.cuda.stream(stream):
-            per = time_conv_kernels(unet, Fr, S, B, args.mode, act)
         sym, d = max(per.items(), key=lambda kv: kv[1]['ms'])
         tflops = d['flops'] / (d['ms'] * 1e-3) / 1e12
         gbs = d['bytes'] / (d['ms'] * 1e-3) / 1e9
@@ -369,6 +391,8 @@ def main():
                             'unit': 'GB/s' if hbm_bound else 'TFLOP/s', 'frac': (gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / mfma_peak),
                             'traffic': traffic, 'traffic_source': traffic_source,
                             'kernel': sym, 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
+                            'how': 'HIP events around every conv launch of 3 eager steps of the timed loop (library hook); '
+                                   f'empty event pair = {ev_overhead_us:.1f} us, subtracted',
                             'avg_algorithmic_mb_per_launch': d['bytes'] / d['launches'] / 1e6,
                             'avg_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
                             'arithmetic_intensity_flop_per_byte': d['flops'] / d['bytes'],

@@ -85,6 +85,20 @@ typedef struct {
  * + scale/shift + SiLU; utils.py:103-125 Up/Downsample; modules.py:219-222 res_conv). */
 int vdx_conv_forward(int mode, const vdx_conv_desc* d, void* stream);
 
+/* Instrumentation (bench.py's roofline leg): a process-global hook the library calls immediately before (phase 0) and after
+ * (phase 1) EVERY convolution launch -- inside vdx_unet_forward / vdx_p_sample_loop too -- with the kernel it dispatched, so that
+ * a caller can bracket each launch with its own events on `stream` while the real step runs.  NULL disables.  Not for use while
+ * a stream is being captured into a graph (run the loop with use_graph = 0). */
+typedef struct {
+    int kernel;                   /* 0 conv_igemm_kernel, 1 conv64p_kernel, 2 conv128x64p_kernel, 3 conv3x3_ws_kernel */
+    int mode, bc, nw, inf;        /* conv_igemm template arguments <mode, BC, 2, NW, INF> */
+    int geo, pro;                 /* conv3x3_ws <GEO, PRO>; conv64p <IN16, PRO, OUT16> uses x_bf16 / pro / y_bf16 */
+    int x_bf16, y_bf16;
+    int cin, cout, h, w, nf, taps, kind, stride;     /* nf = batch * frames; kind 1 = ConvTranspose (4 phases, one launch) */
+} vdx_conv_launch_info;
+typedef void (*vdx_conv_launch_hook)(void* user, int phase, const vdx_conv_launch_info* info, void* stream);
+void vdx_set_conv_launch_hook(vdx_conv_launch_hook hook, void* user);
+
 /* ResnetBlock tail: out = SiLU(GroupNorm(y2; stats, gn_gamma, gn_beta)) + LayerNorm_C(r; ln_gamma, ln_beta)
  * (reference: modules.py:173-179 for Block 2 and :240-243 `h + norm_2(res_conv(x))`).  r is res_conv(x), or x itself
  * when the block has no res_conv.  All tensors channel-last [batch, pix_per_sample, c]. */

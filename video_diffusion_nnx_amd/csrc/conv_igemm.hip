@@ -19,6 +19,7 @@
 #include "vdx_internal.h"
 #include "model.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace vdx {
 
@@ -951,6 +952,24 @@ hipError_t launch_pack_weights_t(int mode, const float* src, void* dst, int taps
     return hipGetLastError();
 }
 
+// instrumentation hook (vdx.h: vdx_set_conv_launch_hook)
+static vdx_conv_launch_hook g_conv_hook = nullptr;
+static void* g_conv_hook_user = nullptr;
+void set_conv_launch_hook(vdx_conv_launch_hook hook, void* user) { g_conv_hook = hook; g_conv_hook_user = user; }
+namespace {
+struct HookScope {
+    vdx_conv_launch_info info; hipStream_t st;
+    HookScope(int mode, const ConvArgs& a, hipStream_t s, int kernel, int bc = 0, int nw = 0, int inf = 0, int geo = 0) : st(s) {
+        memset(&info, 0, sizeof(info));
+        info.kernel = kernel; info.mode = mode; info.bc = bc; info.nw = nw; info.inf = inf; info.geo = geo; info.pro = a.pro;
+        info.x_bf16 = a.x0_bf16; info.y_bf16 = a.y_bf16; info.cin = a.C0 + a.C1; info.cout = a.Cout; info.h = a.H; info.w = a.W; info.nf = a.NF;
+        info.taps = a.kind ? 16 : a.kh * a.kw; info.kind = a.kind; info.stride = a.stride;
+        if (g_conv_hook) g_conv_hook(g_conv_hook_user, 0, &info, st);
+    }
+    ~HookScope() { if (g_conv_hook) g_conv_hook(g_conv_hook_user, 1, &info, st); }
+};
+}  // namespace
+
 hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     // geometry completion
     const int K = a.kind ? 2 : a.kh;
@@ -963,19 +982,26 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     const size_t b0 = npix * a.C0 * (a.x0_bf16 ? 2 : 4), b1 = npix * a.C1 * (a.x1_bf16 ? 2 : 4), bw = (size_t)(a.kind ? 16 : a.kh * a.kw) * a.wrows * a.CinPad * ES;
     if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
     a.x0_bytes = (unsigned)b0; a.x1_bytes = (unsigned)b1; a.w_bytes = (unsigned)bw;
-    if (conv3x3_ws_eligible(mode, a)) return launch_conv3x3_ws(a, st);       // wide levels: persistent weight-streaming kernel
+    if (conv3x3_ws_eligible(mode, a)) {                                      // wide levels: persistent weight-streaming kernel
+        HookScope hs(mode, a, st, 3, 0, 0, 0, conv3x3_ws_geo(a));
+        return launch_conv3x3_ws(a, st);
+    }
     {   // persistent specialisation for the level-0 shape (see conv64p_kernel)
         const int use64p = 1;
         const long tiles = (long)a.NF * (a.H / 16) * (a.W / 16);
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.C0 == 64 && a.C1 == 0 && a.Cout == 64 &&
             a.wrows == 64 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
-            (!a.out_stats || (a.out_groups <= 32 && 64 % a.out_groups == 0)))
+            (!a.out_stats || (a.out_groups <= 32 && 64 % a.out_groups == 0))) {
+            HookScope hs(mode, a, st, 1);
             return launch_conv64p(a, st);
+        }
         const bool in16c = a.x0_bf16 && (!a.C1 || a.x1_bf16);
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.Cout == 64 && in16c && !a.pro &&
             ((a.C0 == 64 && a.C1 == 64) || (a.C0 == 128 && a.C1 == 0)) && a.wrows == 64 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 &&
-            tiles >= 1024 && (!a.out_stats || (a.out_groups <= 32 && 32 % (64 / a.out_groups) == 0 && 64 % a.out_groups == 0)))
+            tiles >= 1024 && (!a.out_stats || (a.out_groups <= 32 && 32 % (64 / a.out_groups) == 0 && 64 % a.out_groups == 0))) {
+            HookScope hs(mode, a, st, 2);
             return launch_conv128x64p(a, st);
+        }
     }
     // variant: 64-channel tiles take 256 pixels per workgroup (stride 1) so every wave owns a 64x64 tile
     const int BC = a.Cout <= 64 ? 64 : 128;
@@ -996,6 +1022,7 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     dim3 grid((a.NF / a.NP) * a.tiles_y * a.tiles_x, (a.Cout + BC - 1) / BC, a.kind ? 4 : 1);
     const bool in16 = mode == MODE_BF16 && a.x0_bf16 && (!a.C1 || a.x1_bf16) && (a.C0 % 8 == 0) && (a.C1 % 8 == 0);
     const int inf = in16 ? 2 : (!a.x0_bf16 && !(a.C1 && a.x1_bf16)) ? 0 : (mode == MODE_BF16 && a.x0_bf16 && !a.C1) ? 1 : 3;
+    HookScope hs(mode, a, st, 0, BC, (BC == 128 || TN == 4) ? 8 : 4, (mode == MODE_BF16 || inf == 0) ? inf : 3);
 #define VDX_LAUNCH_CONV_K(KFN_, NTH_)                                                                    \
     do {                                                                                                  \
         auto kfn = KFN_;                                                                                  \

@@ -432,6 +432,8 @@ static int ws_geo(const ConvArgs& a) {                    // 0: 16 x 16 tiles, 8
     return -1;
 }
 
+int conv3x3_ws_geo(const ConvArgs& a) { return ws_geo(a); }
+
 bool conv3x3_ws_eligible(int mode, const ConvArgs& a) {
     if (mode != MODE_BF16 || a.kind != 0 || a.kh != 3 || a.kw != 3 || a.stride != 1 || a.res) return false;
     if (!a.x0_bf16 || (a.C1 && !a.x1_bf16)) return false;

@@ -72,6 +72,8 @@ int vdx_pack_conv_weights(int mode, const float* kernel, void* packed, int taps,
     return VDX_OK;
 }
 
+void vdx_set_conv_launch_hook(vdx_conv_launch_hook hook, void* user) { vdx::set_conv_launch_hook(hook, user); }
+
 size_t vdx_gn_stats_bytes(int batch, int groups) { return (size_t)batch * 32 /*GN_SLOTS*/ * groups * 2 * sizeof(double); }
 
 int vdx_conv_forward(int mode, const vdx_conv_desc* d, void* stream) {
