@@ -146,6 +146,15 @@ def time_convs_in_step(run_eager, dev, mode, steps=3):
     finally:
         set_hook(C.cast(None, HOOK), None)
     per_symbol = {}
+    if os.environ.get('VDX_BENCH_CONV_DETAIL'):                      # per-shape table on stderr (diagnostics)
+        shapes = {}
+        for info, e0, e1 in records:
+            k = (conv_symbol(info), info.cin, info.cout, info.h, info.taps, info.kind, info.stride, info.pro)
+            v = shapes.setdefault(k, [0, 0.0, conv_info_work(info, mode)[0]])
+            v[0] += 1; v[1] += max(e0.elapsed_time(e1) - overhead_ms, 0.0)
+        for k, (n, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+            log(f'  {k[0][5:46]:42s} cin {k[1]:4d} cout {k[2]:4d} h {k[3]:3d} taps {k[4]:2d} kind {k[5]} s {k[6]} pro {k[7]}: '
+                f'{n // steps:2d}/step x {ms / n * 1e3:7.1f} us  {fl / (ms / n * 1e-3) / 1e12:6.0f} TF')
     for info, e0, e1 in records:
         fl, by = conv_info_work(info, mode)
         d = per_symbol.setdefault(conv_symbol(info), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))

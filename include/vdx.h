@@ -129,6 +129,11 @@ int vdx_time_mlp(const int* time, const float* w1, const float* b1, const float*
 int vdx_attention_forward(int mode, const float* x, float* y, const void* wqkv_packed, const float* bqkv,
                           const void* wo_packed, const float* bo, int batch, int frames, int h, int w, int c, int heads,
                           int temporal, void* stream);
+/* Same; fp8_core != 0 (VDX_MODE_BF16 only): QK^T and PV of sequences of <= 16 tokens on e4m3 operands (see vdx_set_attention_fp8;
+ * longer sequences ignore the flag). */
+int vdx_attention_forward_ex(int mode, const float* x, float* y, const void* wqkv_packed, const float* bqkv,
+                             const void* wo_packed, const float* bo, int batch, int frames, int h, int w, int c, int heads,
+                             int temporal, int fp8_core, void* stream);
 
 /* SpatialLinearAttention + residual (reference: modules.py:64-129 inside Residual(PreNorm(..)), unet3d.py:170-178).
  * heads must be 8, head dim 32.  wq/wk/wv_packed: packed [C,256]; wo_packed: packed [256,C].
@@ -172,6 +177,14 @@ void vdx_destroy(vdx_handle* h);
  * has no such knob (XLA picks its own buffer types); this is the "bf16" of BASELINE.json's sampling configuration. */
 int vdx_set_activation_storage(vdx_handle* h, int bf16);
 int vdx_get_activation_storage(const vdx_handle* h);
+
+/* fp8 attention (BASELINE.json configs[4]: "fp8 attention QK^T / PV on CDNA4"; no reference counterpart -- XLA picks its own types).
+ * VDX_MODE_BF16 handles only, forward / sampling only.  1: the QK^T and PV products of every attention block over <= 16 tokens (all
+ * temporal attention blocks of the configured shapes) round their operands (q, k, v, softmax probabilities) to OCP e4m3 and run on
+ * v_mfma_f32_16x16x32_fp8_fp8, fp32 accumulate and fp32 softmax; projections stay bf16.  Longer sequences (the 64-token spatial block
+ * of the bottleneck) keep bf16 operands.  Tolerance: tests/test_gpu_blocks.py (attention block 4e-2 of the attention branch). */
+int vdx_set_attention_fp8(vdx_handle* h, int on);
+int vdx_get_attention_fp8(const vdx_handle* h);
 
 /* Flat fp32 parameter buffer layout (names = nnx state-tree paths, shapes = Flax shapes). */
 int vdx_param_count(const vdx_handle* h);

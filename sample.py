@@ -1,7 +1,8 @@
 """Sampling CLI for the MI355X path.  Accepts the reference CLI's flags (reference sample.py:19-62: --config,
 --output-path, --checkpoint-path, --step, --seed, --batch-size, --load-ema-params) and its YAML schema, then runs
 GaussianDiffusion.sample on the GPU and writes one GIF per video (batch-global min-max to uint8, 120 ms/frame).
-Extensions: --mode {bf16,f16,f32}; --random-init (no checkpoint); --timesteps N (shorter chain for smoke runs); --ddim-steps S."""
+Extensions: --mode {bf16,f16,f32}; --random-init (no checkpoint); --timesteps N (shorter chain for smoke runs); --ddim-steps S;
+--attn-fp8 (bf16 mode: QK^T / PV of the <= 16-token attention blocks on fp8 MFMA operands)."""
 import argparse
 import logging
 import pathlib
@@ -21,15 +22,16 @@ FLAGS = (   # (flag, kwargs)
     ('--random-init', dict(action='store_true', help='skip the checkpoint, use freshly initialised weights')),
     ('--timesteps', dict(type=int, default=None, help='override diffusion.timesteps')),
     ('--ddim-steps', dict(type=int, default=None, help='sample with an S-step DDIM chain (eta = 0) instead of the T-step ancestral one')),
+    ('--attn-fp8', dict(action='store_true', help='bf16 mode: fp8 (e4m3) QK^T / PV in the attention blocks over <= 16 tokens')),
 )
 
 
-def build_models(cfg, mode, timesteps=None):
+def build_models(cfg, mode, timesteps=None, attn_fp8=False):
     from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
     from video_diffusion_nnx_amd.unet3d import Rngs, Unet3D
     u, d = cfg['unet'], cfg['diffusion']
     unet = Unet3D(dim=u['dim'], rngs=Rngs(u['rngs_seed']), dim_mults=tuple(u['dim_mults']), channels=u['channels'],
-                  use_bert_text_cond=u['use_bert_text_cond'], mode=mode)
+                  use_bert_text_cond=u['use_bert_text_cond'], mode=mode, attn_fp8=attn_fp8)
     gd = GaussianDiffusion(denoise_fn=unet, image_size=d['image_size'], num_frames=d['num_frames'], channels=d['channels'],
                            timesteps=timesteps or d['timesteps'], loss_type=d['loss_type'])
     return unet, gd
@@ -52,7 +54,7 @@ def main(argv=None):
     with open(a.config) as fh:
         cfg = yaml.safe_load(fh)
     logging.info('config %s', a.config)
-    _, gd = build_models(cfg, a.mode, a.timesteps)
+    _, gd = build_models(cfg, a.mode, a.timesteps, attn_fp8=a.attn_fp8)
     if not a.random_init:
         ckpt = pathlib.Path(a.checkpoint_path).resolve()
         gd, _ = load_checkpoint(gd, a.step, str(ckpt), load_ema_params=a.load_ema_params)

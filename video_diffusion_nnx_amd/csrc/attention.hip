@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs P) {
 //                                          B = the normalised scores, still in their accumulator registers
 //   y[c,i]   += sum_d Wo[c, h*32+d] O^T[d,i] : B = the O^T accumulator tiles, A = 4-element weight fragments from L2
 // never leave the register file: no q/k/v/P/O round trips through LDS, two workgroup barriers per head (weight tile only).
-template <int MODE, int TMA>            // TMA = C / 16 output-channel tiles (all owned by every wave, for its 16 rows)
+template <int MODE, int TMA, bool F8>   // TMA = C / 16 output-channel tiles (all owned by every wave, for its 16 rows); F8: fp8 QK^T / PV
 __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
     using M = Mma<MODE>;
     constexpr int KT = M::KT, RS = ROW_STRIDE;
@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
         }
         // S^T[j, i]: lane (i, q) holds keys j = 4q..4q+3
         f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
-        M::mma16(s, ak[0], aq[0]);
-        M::mma16(s, ak[1], aq[1]);
+        core_mma16<M, F8>(s, ak[0], aq[0]);
+        core_mma16<M, F8>(s, ak[1], aq[1]);
         float mx = -1e30f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { if (4 * q + r >= P.L) s[r] = -1e30f; mx = fmaxf(mx, s[r]); }
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-            M::mma16(o, av[t], s);
+            core_mma16<M, F8>(o, av[t], s);
 #pragma unroll
             for (int tm = 0; tm < TMA; ++tm) {
                 const f32x4 a = M::load_w4(wos + (tm * 16 + lp) * WOS + (t * 16 + 4 * q) * M::ES);
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
 // nseq % 4 == 0 (the 4 sequences of a sub-tile share their outer index) and 32-bit per-thread offsets.
 // IO16: x and y are bf16 tensors (bf16 activation storage): pieces are 8 channels = 16 bytes, copied into the bf16 LDS tile
 // as they are, and the raw piece is the residual.
-template <int MODE, int NKT, int TMO, int TNO, bool IO16>
+template <int MODE, int NKT, int TMO, int TNO, bool IO16, bool F8>
 __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, const int nsub) {
     using M = Mma<MODE>;
     static_assert(!IO16 || MODE == MODE_BF16, "bf16 activation storage implies bf16 MFMA operands");
@@ -544,8 +544,8 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
                     }
                 }
             f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};      // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
-            M::mma16(sc, ak[0], aq[0]);
-            M::mma16(sc, ak[1], aq[1]);
+            core_mma16<M, F8>(sc, ak[0], aq[0]);
+            core_mma16<M, F8>(sc, ak[1], aq[1]);
             if (masked) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (4 * q + r >= P.L) sc[r] = -1e30f;
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
 #pragma unroll
             for (int t = 0; t < 2; ++t) {              // O^T[d, i] -> os[row i][h*32 + d]
                 f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-                M::mma16(o, av[t], sc);
+                core_mma16<M, F8>(o, av[t], sc);
                 M::store4(os + (sl * 16 + lp) * RSO, h * D + t * 16 + 4 * q, make_float4(o[0], o[1], o[2], o[3]));
             }
         }
@@ -609,11 +609,11 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     }
 }
 
-template <int MODE, int NKT, int TMO, int TNO, bool IO16>
+template <int MODE, int NKT, int TMO, int TNO, bool IO16, bool F8 = false>
 static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
     using M = Mma<MODE>;
     const size_t lds = 2 * (size_t)NKT * 64 * ROW_STRIDE + (size_t)64 * (256 * M::ES + 16) + (size_t)64 * (NKT * M::KT * 4 + 16);
-    auto kfn = attention_h8_kernel<MODE, NKT, TMO, TNO, IO16>;
+    auto kfn = attention_h8_kernel<MODE, NKT, TMO, TNO, IO16, F8>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -633,7 +633,7 @@ static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
 // every wave then walks its own sequences with no workgroup barrier: x fragments (16 tokens x 32 channels) come straight from
 // global memory / L2 (each x row is read by the 8 head-workgroups), weight fragments from LDS, and the core runs in registers as in
 // attention_reg_kernel.  Output: O[row][head*32 + d] bf16; the out-projection (+bias, +residual) is a plain 1x1 conv_igemm.
-template <bool IO16, int TT>
+template <bool IO16, int TT, bool F8>
 __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, const int seq_per_block, const int nchunks) {
     // TT sequences per wave at a time: each weight fragment read from LDS feeds TT MFMAs (one sequence per read would make the kernel
     // LDS-bandwidth bound: 6 KB of fragments per 6 MFMAs per wave), and the x fragments run through a 4-deep register ring so that
@@ -738,8 +738,8 @@ __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, c
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
             f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};                     // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
-            M::mma16(sc, ak[tt][0], aq[tt][0]);
-            M::mma16(sc, ak[tt][1], aq[tt][1]);
+            core_mma16<M, F8>(sc, ak[tt][0], aq[tt][0]);
+            core_mma16<M, F8>(sc, ak[tt][1], aq[tt][1]);
             if (masked) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (4 * q + r >= P.L) sc[r] = -1e30f;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, c
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-                M::mma16(o, av[tt][t], sc);
+                core_mma16<M, F8>(o, av[tt][t], sc);
                 if (crow[tt] >= 0) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.oscratch) + ((size_t)crow[tt] * HD + h * D + t * 16 + 4 * q) * 2) =
                                        make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
             }
@@ -780,14 +780,18 @@ hipError_t launch_attention_heads(AttnArgs a, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3((unsigned)((chunks + 7) / 8 * 64)), dim3(512), lds, st, a, (int)spb, (int)chunks);
         return hipGetLastError();
     };
-    return a.io_bf16 ? go(attention_head_kernel<true, TT>) : go(attention_head_kernel<false, TT>);
+    if (a.fp8_core) return a.io_bf16 ? go(attention_head_kernel<true, TT, true>) : go(attention_head_kernel<false, TT, true>);
+    return a.io_bf16 ? go(attention_head_kernel<true, TT, false>) : go(attention_head_kernel<false, TT, false>);
 }
 
 template <int MODE, int TMA>
 static hipError_t launch_attn_reg_t(const AttnArgs& a, hipStream_t st) {
     const size_t lds = 512 + (size_t)(64 + 96) * ROW_STRIDE + (size_t)TMA * 16 * (32 * Mma<MODE>::ES + 16);
     const long blocks = (a.nseq + 3) / 4;
-    hipLaunchKernelGGL((attention_reg_kernel<MODE, TMA>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    if constexpr (MODE == MODE_BF16) {
+        if (a.fp8_core) { hipLaunchKernelGGL((attention_reg_kernel<MODE, TMA, true>), dim3((unsigned)blocks), dim3(256), lds, st, a); return hipGetLastError(); }
+    }
+    hipLaunchKernelGGL((attention_reg_kernel<MODE, TMA, false>), dim3((unsigned)blocks), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
@@ -838,6 +842,12 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
     if (h8_ok && use_reg && use_h8) {
         const int nkt = a.CPad / Mma<MODE>::KT;
         if constexpr (MODE == MODE_BF16) {
+            if (a.fp8_core) {                                 // fp8 QK^T / PV (vdx_set_attention_fp8)
+                if (a.io_bf16 && a.C == 64) return launch_attn_h8_t<MODE, 1, 1, 2, true, true>(a, st);
+                if (a.io_bf16 && a.C == 128) return launch_attn_h8_t<MODE, 2, 1, 4, true, true>(a, st);
+                if (a.C == 64 && nkt == 1) return launch_attn_h8_t<MODE, 1, 1, 2, false, true>(a, st);
+                if (a.C == 128 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 4, false, true>(a, st);
+            }
             if (a.io_bf16 && a.C == 64) return launch_attn_h8_t<MODE, 1, 1, 2, true>(a, st);
             if (a.io_bf16 && a.C == 128) return launch_attn_h8_t<MODE, 2, 1, 4, true>(a, st);
         }

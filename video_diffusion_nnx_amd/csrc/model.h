@@ -32,6 +32,7 @@ struct Level {
 struct Model {
     vdx_config cfg;
     int mode, init_dim, out_dim, time_dim, temb_dim;
+    int attn_fp8 = 0;                    // bf16 mode only: QK^T / PV of the <= 16-token attention cores on fp8 operands (forward only)
     int act16 = 0;                       // bf16 mode only: store every inter-kernel activation as bf16 (inference; the backward reads fp32 slots)
     std::vector<ParamInfo> params; long param_total = 0;
     size_t packed_bytes = 0;

@@ -405,6 +405,7 @@ static hipError_t run_attn(const Fwd& f, const AttnP& ap, const float* x, float*
     if (temporal) { a.L = (int)Fr; a.nseq = f.B * hw; a.inner = hw; a.inner_stride = ap.C; a.outer_stride = Fr * hw * ap.C; a.tok_stride = hw * ap.C; }
     else { a.L = (int)hw; a.nseq = f.B * Fr; a.inner = 1; a.inner_stride = 0; a.outer_stride = hw * ap.C; a.tok_stride = ap.C; }
     a.io_bf16 = f.a16;
+    a.fp8_core = (m->attn_fp8 && m->mode == MODE_BF16) ? 1 : 0;
     if (a.L > 64) {
         // long sequences (spatial attention of a bottleneck larger than 8 x 8): q|k|v projection and out-projection (+ bias + residual)
         // as 1x1 convs around the fp32 core of attention.hip; token-major rows = the channel-last tensor as it is

@@ -160,6 +160,13 @@ int vdx_time_mlp(const int* time, const float* w1, const float* b1, const float*
 int vdx_attention_forward(int mode, const float* x, float* y, const void* wqkv_packed, const float* bqkv,
                           const void* wo_packed, const float* bo, int batch, int frames, int h, int w, int c, int heads,
                           int temporal, void* stream) {
+    return vdx_attention_forward_ex(mode, x, y, wqkv_packed, bqkv, wo_packed, bo, batch, frames, h, w, c, heads, temporal, 0, stream);
+}
+
+int vdx_attention_forward_ex(int mode, const float* x, float* y, const void* wqkv_packed, const float* bqkv,
+                             const void* wo_packed, const float* bo, int batch, int frames, int h, int w, int c, int heads,
+                             int temporal, int fp8_core, void* stream) {
+    if (fp8_core && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "attention: the fp8 core needs VDX_MODE_BF16");
     if (!x || !y || !wqkv_packed || !bqkv || !wo_packed || !bo) VDX_FAIL(VDX_ERR_INVALID, "attention: null tensor");
     if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16 && mode != VDX_MODE_F16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
     if (c % 4 || c > 512 || heads < 1) VDX_FAIL(VDX_ERR_INVALID, "attention: C must be a multiple of 4 and <= 512");
@@ -174,6 +181,7 @@ int vdx_attention_forward(int mode, const float* x, float* y, const void* wqkv_p
         a.L = (int)hw; a.nseq = (long)batch * frames; a.inner = 1; a.inner_stride = 0; a.outer_stride = hw * c; a.tok_stride = c;
     }
     if (a.L > 64) VDX_FAIL(VDX_ERR_INVALID, "attention: more than 64 tokens per sequence is not supported");
+    a.fp8_core = fp8_core ? 1 : 0;
     VDX_HIP(vdx::launch_attention(mode, a, (hipStream_t)stream));
     return VDX_OK;
 }
@@ -243,6 +251,15 @@ int vdx_set_activation_storage(vdx_handle* h, int bf16) {
     return VDX_OK;
 }
 int vdx_get_activation_storage(const vdx_handle* h) { return h ? h->model.act16 : 0; }
+
+int vdx_set_attention_fp8(vdx_handle* h, int on) {
+    if (!h) VDX_FAIL(VDX_ERR_INVALID, "set_attention_fp8: null handle");
+    if (on && h->model.mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "fp8 attention needs a VDX_MODE_BF16 handle");
+    const int v = on ? 1 : 0;
+    if (v != h->model.attn_fp8) { h->drop_graphs(); h->model.attn_fp8 = v; }
+    return VDX_OK;
+}
+int vdx_get_attention_fp8(const vdx_handle* h) { return h ? h->model.attn_fp8 : 0; }
 
 int vdx_param_count(const vdx_handle* h) { return h ? (int)h->model.params.size() : 0; }
 long vdx_param_total(const vdx_handle* h) { return h ? h->model.param_total : 0; }
@@ -539,6 +556,7 @@ int vdx_unet_backward(vdx_handle* h, const float* params, const void* packed, co
     if (!h || !params || !packed || !packed_t || !x || !time || !d_out || !fwd_workspace || !bwd_workspace || !grads) VDX_FAIL(VDX_ERR_INVALID, "unet_backward: null argument");
     if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "unet_backward: handle was created without a GPU");
     if (h->model.act16) VDX_FAIL(VDX_ERR_STATE, "unet_backward: the forward ran with bf16 activation storage; the backward reads fp32 slots");
+    if (h->model.attn_fp8) VDX_FAIL(VDX_ERR_STATE, "unet_backward: fp8 attention is a forward (sampling) option; the backward differentiates the bf16 cores");
     return vdx::model_backward(&h->model, &h->bwd, params, packed, packed_t, x, time, cond, cond_mask, null_all, d_out, fwd_workspace,
                                bwd_workspace, bwd_workspace_bytes, grads, stage_hi, stage_lo, batch, (hipStream_t)stream);
 }

@@ -89,6 +89,14 @@ template <> struct Mma<MODE_BF16> {
         const uint2 ub = make_uint2(pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3]));
         acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, ua), __builtin_bit_cast(s16x4, ub), acc, 0, 0, 0);
     }
+    // attention-core variant (BASELINE.json configs[4], "fp8 attention QK^T / PV"): both operands rounded to OCP e4m3 (gfx950's
+    // v_cvt_pk_fp8_f32), fp32 accumulate.  The 4 values of an accumulator-layout operand fill K slots 0..3 of the lane's 8 of
+    // v_mfma_f32_16x16x32_fp8_fp8, slots 4..7 are zero on both sides: the same K = 16 product as mma16.
+    static __device__ __forceinline__ void mma16_fp8(f32x4& acc, const f32x4& a, const f32x4& b) {
+        int ua = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], 0, false); ua = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], ua, true);
+        int ub = __builtin_amdgcn_cvt_pk_fp8_f32(b[0], b[1], 0, false); ub = __builtin_amdgcn_cvt_pk_fp8_f32(b[2], b[3], ub, true);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8((long)(unsigned)ua, (long)(unsigned)ub, acc, 0, 0, 0);
+    }
     static __device__ __forceinline__ f32x4 load_w4(const char* p) {
         const uint2 u = *reinterpret_cast<const uint2*>(p);
         return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xFFFF0000u)};
@@ -140,6 +148,11 @@ template <> struct Mma<MODE_F16> {
         *reinterpret_cast<_Float16*>(row + k * 2) = (_Float16)v;
     }
 };
+
+// QK^T / PV product of the <= 16-token attention cores: fp8 operands when F8 (bf16 mode only), the mode's K = 16 product otherwise
+template <class M, bool F8> __device__ __forceinline__ void core_mma16(f32x4& acc, const f32x4& a, const f32x4& b) {
+    if constexpr (F8) M::mma16_fp8(acc, a, b); else M::mma16(acc, a, b);
+}
 
 // one packed-weight element of the mode's operand type
 template <int MODE> __device__ __forceinline__ void store_operand(void* dst, size_t i, float v) {

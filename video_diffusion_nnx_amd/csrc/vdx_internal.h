@@ -79,6 +79,7 @@ struct AttnArgs {
     long nseq, inner, inner_stride, outer_stride, tok_stride;
     float scale;
     int io_bf16;                              // x and y stored as bf16 (bf16 activation storage); strides stay in elements
+    int fp8_core;                             // bf16 mode, <= 16 tokens: QK^T and PV on fp8 (e4m3) MFMA operands (vdx_set_attention_fp8)
     void* oscratch;                           // [rows][heads*32] bf16: per-head attention output of launch_attention_heads
     int CPad, HDPad;                          // completed by the launcher
 };

@@ -108,12 +108,12 @@ def pack_mha(pq, pk, pv, po, mode):
     return pack_conv_weights(wqkv, mode), bqkv, pack_conv_weights(wo, mode), po[1].contiguous()
 
 
-def attention_forward(x, packed, heads, temporal, mode):
+def attention_forward(x, packed, heads, temporal, mode, fp8_core=False):
     B, Fr, H, W, C_ = x.shape
     y = torch.empty_like(x)
     wqkv, bqkv, wo, bo = packed
-    L.check(L.vdx_attention_forward(_mode(mode), L.ptr(x), L.ptr(y), L.ptr(wqkv), L.ptr(bqkv), L.ptr(wo), L.ptr(bo),
-                                    B, Fr, H, W, C_, heads, int(temporal), L.stream_ptr()))
+    L.check(L.vdx_attention_forward_ex(_mode(mode), L.ptr(x), L.ptr(y), L.ptr(wqkv), L.ptr(bqkv), L.ptr(wo), L.ptr(bo),
+                                       B, Fr, H, W, C_, heads, int(temporal), int(bool(fp8_core)), L.stream_ptr()))
     return y
 
 

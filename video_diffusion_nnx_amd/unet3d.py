@@ -58,6 +58,7 @@ vdx_slot_count = L._sig('vdx_slot_count', C.c_int, [_vp])
 vdx_slot_info = L._sig('vdx_slot_info', C.c_int, [_vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)])
 vdx_num_stages = L._sig('vdx_num_stages', C.c_int, [_vp])
 vdx_set_activation_storage = L._sig('vdx_set_activation_storage', C.c_int, [_vp, C.c_int])
+vdx_set_attention_fp8 = L._sig('vdx_set_attention_fp8', C.c_int, [_vp, C.c_int])
 vdx_get_activation_storage = L._sig('vdx_get_activation_storage', C.c_int, [_vp])
 vdx_packed_bwd_bytes = L._sig('vdx_packed_bwd_bytes', C.c_size_t, [_vp])
 vdx_pack_params_bwd = L._sig('vdx_pack_params_bwd', C.c_int, [_vp, _vp, _vp, _vp])
@@ -111,13 +112,14 @@ def _trunc_normal(rng: np.random.Generator, shape, std: float) -> np.ndarray:
 class Unet3D:
     """Space-time factorised 3-D U-Net denoiser (reference unet3d.py:58-75 signature).
 
-    Extra keyword `mode` ('bf16' | 'f16' | 'f32') selects the MFMA arithmetic; `device` the GPU.
+    Extra keyword `mode` ('bf16' | 'f16' | 'f32') selects the MFMA arithmetic; `device` the GPU; `attn_fp8` (mode 'bf16', forward /
+    sampling only) runs QK^T and PV of the <= 16-token attention blocks on fp8 (e4m3) MFMA operands (BASELINE.json configs[4]).
     """
 
     def __init__(self, dim: int, rngs=0, dim_mults=(1, 2, 4, 8), cond_dim=None, out_dim=None, channels=3,
                  attn_heads=8, attn_dim_head=32, use_bert_text_cond=False, init_dim=None, init_kernel_size=7,
                  use_sparse_linear_attn=True, block_type='resnet', resnet_groups=8, log_dims=False,
-                 *, mode: str = 'bf16', device=None):
+                 *, mode: str = 'bf16', device=None, attn_fp8: bool = False):
         assert init_kernel_size % 2 == 1                                       # unet3d.py:105
         self.dim = dim
         self.dim_mults = tuple(dim_mults)
@@ -136,6 +138,9 @@ class Unet3D:
         # bf16 mode only: store every inter-kernel activation as bf16 (inference).  GaussianDiffusion turns it on for its
         # sampling loops; forwards that feed backward() need it off (the backward reads the fp32 slots).
         self.act_bf16 = False
+        if attn_fp8 and mode != 'bf16':
+            raise ValueError("attn_fp8 needs mode='bf16'")
+        self.attn_fp8 = bool(attn_fp8)
         # default: the process's CURRENT device (a rank launched by torch.distributed.run has called set_device(LOCAL_RANK))
         if device is not None:
             self.device = torch.device(device)
@@ -302,6 +307,7 @@ class Unet3D:
         if self.act_bf16 and self.mode != 'bf16':
             raise ValueError("act_bf16 needs mode='bf16'")
         L.check(vdx_set_activation_storage(h.ptr, int(bool(self.act_bf16))))
+        L.check(vdx_set_attention_fp8(h.ptr, int(self.attn_fp8)))
 
     def workspace(self, batch: int, frames: int, size: int) -> torch.Tensor:
         key = (batch, frames, size)
