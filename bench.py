@@ -203,6 +203,7 @@ def parse_args(argv=None):
     ap.add_argument('--size', type=int, default=64)
     ap.add_argument('--act-storage', default=os.environ.get('VDX_BENCH_ACT', 'auto'), choices=['auto', 'f32', 'bf16'],
                     help='storage of the inter-kernel activations (auto: bf16 in bf16 mode, as GaussianDiffusion.sample does)')
+    ap.add_argument('--attn-fp8', action='store_true', help='bf16 mode: fp8 (e4m3) QK^T / PV in the <= 16-token attention blocks (BASELINE configs[4]); off by default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-train', action='store_true', help='skip the training leg (p_losses fwd+bwd, bucketed all-reduce, Adam/EMA)')
@@ -311,7 +312,7 @@ def main():
     from video_diffusion_nnx_amd.unet3d import Unet3D
 
     B, Fr, S = args.batch, args.frames, args.size
-    unet = Unet3D(dim=args.dim, rngs=0, channels=1, mode=args.mode, device=dev)
+    unet = Unet3D(dim=args.dim, rngs=0, channels=1, mode=args.mode, device=dev, attn_fp8=args.attn_fp8)
     gd = GaussianDiffusion(unet, image_size=S, num_frames=Fr, channels=1, timesteps=T_STEPS, loss_type='l2')
     h = unet.handle(Fr, S)
     act = args.act_storage if args.act_storage != 'auto' else ('bf16' if args.mode == 'bf16' else 'f32')
@@ -365,7 +366,7 @@ def main():
         'config': {'workload': f'config_v2_2 (north-star shape): Unet3D dim={args.dim} C=1, {Fr}f x {S}x{S}, DDPM T={T_STEPS} p_sample_loop '
                                f'(UNet forward + p_sample per step, hipGraph replay); value = n_gpus*B*F/(T*s_per_step)',
                    'batch_per_gpu': B, 'timesteps': T_STEPS, 'parallelism': f'dp{world} (independent samples, no collective)',
-                   'mfma_operands': args.mode, 'storage': f'weights fp32 master, activations {act}, fp32 accumulate',
+                   'mfma_operands': args.mode + (' (attention QK^T / PV: fp8 e4m3)' if args.attn_fp8 else ''), 'storage': f'weights fp32 master, activations {act}, fp32 accumulate',
                    'process_group': backend or 'none (single process)'},
     }
     log(f'timed region done: {ms_per_step:.3f} ms/step')
