@@ -17,6 +17,7 @@
 // a 2-deep register->LDS ring.  Accumulators: lane (r,q) holds channels 4q..4q+3 of pixel r (vdx_common.h).
 #include "vdx_common.h"
 #include "vdx_internal.h"
+#include "vdx_glds.h"
 #include "model.h"
 #include <stdlib.h>
 #include <string.h>
@@ -41,7 +42,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
     constexpr int NT = 64 * NW;                     // threads per workgroup
     constexpr int TM = 4;
     constexpr int APIECES = KT / 4;                 // float4 pieces per staged pixel row
-    constexpr int WREGS = BC * 8 / NT;              // 16-byte weight pieces per thread per tap
+    constexpr int WREGS = BC * 8 / NT;              // 16-byte weight pieces per thread per tap = LDS-DMA instructions per wave per slab
+    constexpr int NSW = 3;                          // weight ring: slab t (MFMAs), t + 1 (in flight or landed), t + 2 (being issued)
+    constexpr int SLAB = BC * 128;                  // one (tap, K tile) weight slab: BC rows x 128 bytes, 16-byte chunk c of row r at c ^ (r & 7)
     constexpr int AU = 4;                           // halo-tile loads in flight per thread (one or two batches per tile)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
         gmean = reinterpret_cast<float*>(smem + off); off += 64 * 4;               // [groups<=32][mean, rstd]
     }
     char* As = smem + off; off += (size_t)HPX * RS;
-    char* Ws = smem + off;                                                          // [2][BC rows]
+    char* Ws = smem + off;                                                          // [NSW][BC rows][128 B] (swizzled, filled by LDS-DMA)
 
     for (int i = tid; i < 2 * BC; i += NT) chs[i] = 0.f;
     for (int hp = tid; hp < HPX; hp += NT) {
@@ -138,29 +141,34 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- weight staging: per-thread constant row offsets, per-phase uniform offset -----------------
-    unsigned wvoff[WREGS];
-    int wdst[WREGS];
+    // ---- weight stream: the [tap][BC rows][KT] slabs of the packing flow through a 3-deep LDS ring filled by LDS-DMA
+    //      (global_load_lds_dwordx4, no VGPRs, no ds_write pass), two taps ahead of the MFMAs; ONE raw s_barrier per tap behind a
+    //      counted s_waitcnt vmcnt (conv_ws.hip, round 2; round 1: global -> registers -> LDS one tap ahead + __syncthreads, whose
+    //      vmcnt(0) exposed an L2 round trip per tap: 0.5 us per tap on the 64-256-workgroup grids of training) -----------------
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned wsrc[WREGS];                            // this lane's source byte offsets inside a slab's rows (swizzle on the SOURCE side)
 #pragma unroll
     for (int k = 0; k < WREGS; ++k) {
-        const int row = (tid >> 3) + (NT / 8) * k;
+        const int i = (k * NW + wave) * 64 + lane, row = i >> 3, pos = i & 7;
         const int co = min(c0 + row, P.Cout - 1);     // rows past Cout re-read the last row; their outputs are never stored
-        wvoff[k] = (unsigned)((co + P.wrow0) * P.CinPad) * M::ES + (tid & 7) * 16;
-        wdst[k] = row * RS + (tid & 7) * 16;
+        wsrc[k] = (unsigned)((co + P.wrow0) * P.CinPad) * M::ES + (unsigned)((pos ^ (row & 7)) << 4);
     }
-    const unsigned tap_stride = (unsigned)(P.wrows * P.CinPad) * M::ES;
-    u32x4 wreg[WREGS];
-    auto wload = [&](int dy, int dx, int cc) {
-        const int widx = P.kind ? ((2 * dy + ry) * 4 + (2 * dx + rx)) : (dy * KW + dx);
-        const unsigned so = (unsigned)widx * tap_stride + (unsigned)(cc * KT) * M::ES;
+    const size_t tap_stride = (size_t)P.wrows * P.CinPad * M::ES;
+    const char* wbase = reinterpret_cast<const char*>(P.wp);
+    const unsigned ws_a = lds_addr(Ws);
+    const int cc_lo = 0, cc_hi = nchunks;
+    int pdy = 0, pdx = 0, pcc = cc_lo, pslot = 0;     // prefetch cursor; wraps at the end (two harmless slabs past the last tap keep the wait counts uniform)
+    auto issue_w = [&]() {
+        const int widx = P.kind ? ((2 * pdy + ry) * 4 + (2 * pdx + rx)) : (pdy * KW + pdx);
+        const char* src = wbase + (size_t)widx * tap_stride + (size_t)(pcc * KT) * M::ES;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ws_a + pslot * SLAB + wave_u * 1024);
 #pragma unroll
-        for (int k = 0; k < WREGS; ++k) wreg[k] = __builtin_amdgcn_raw_buffer_load_b128(rsw, wvoff[k], so, 0);
+        for (int k = 0; k < WREGS; ++k) glds16(src + wsrc[k], dst + k * NW * 1024);
+        if (++pdx == KW) { pdx = 0; if (++pdy == KH) { pdy = 0; if (++pcc == cc_hi) pcc = cc_lo; } }
+        if (++pslot == NSW) pslot = 0;
     };
-    auto wstore = [&](int buf) {
-        char* dst = Ws + buf * (BC * RS);
-#pragma unroll
-        for (int k = 0; k < WREGS; ++k) *reinterpret_cast<u32x4*>(dst + wdst[k]) = wreg[k];
-    };
+    // A fragments: row wc*64 + tm*16 + lp of the slab, chunk 4 ch + q at position chunk ^ (row & 7); (row & 7) = (lp & 7)
+    const int aoff = (wc * 64 + lp) * 128 + ((q ^ (lp & 7)) << 4);
 
     // ---- main loop: K tiles of cin x taps --------------------------------------------------------
     const int total = HPX * APIECES;
@@ -168,10 +176,10 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
     const bool x0b = RT ? (P.x0_bf16 != 0) : (INF == 1);
     const bool x1b = RT ? (P.x1_bf16 != 0) : false;
     const bool cat = (INF == 1) ? false : (P.C1 != 0);
-    int buf = 0;
-    wload(0, 0, 0);
-    for (int cc = 0; cc < nchunks; ++cc) {
-        if (cc) __syncthreads();                     // every wave is done reading the previous halo tile
+    int cslot = 0;
+    issue_w(); issue_w();
+    for (int cc = cc_lo; cc < cc_hi; ++cc) {
+        if (cc != cc_lo) __builtin_amdgcn_s_barrier();   // every wave is done reading the previous halo tile (its fragment reads are consumed: MFMAs issued)
         if constexpr (MODE == MODE_BF16 && INF == 2) {
             // every input tensor is bf16: 16-byte pieces of 8 channels, half the loads / address math / LDS writes, and a
             // plain copy into the bf16 tile when there is no prologue
@@ -284,32 +292,33 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
             }
         }
         }
+        __syncthreads();                                  // the halo tile is complete (LDS stores of every wave)
         int dy = 0, dx = 0;
         for (int tap = 0; tap < ntaps; ++tap) {
-            wstore(buf);
-            __syncthreads();
-            int ndy = dy, ndx = dx + 1, ncc = cc;
-            if (ndx == KW) { ndx = 0; ndy = dy + 1; }
-            if (ndy == KH) { ndy = 0; ncc = cc + 1; }
-            if (ncc < nchunks) wload(ndy, ndx, ncc);      // prefetch the next weight tile while this one is consumed
+            // this tap's slab has landed in every wave's part (only the next slab's WREGS LDS-DMAs may still be in flight), and every
+            // wave is done with the slab of the previous tap, whose ring slot the new issue overwrites
+            wait_vm<WREGS>();
+            __builtin_amdgcn_s_barrier();
+            issue_w();
             const int tapoff = (dy * IW + dx) * RS;
-            const char* wt = Ws + buf * (BC * RS) + (wc * 64 + lp) * RS + q * 16;
+            const char* wt = Ws + cslot * SLAB;
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
                 uint4 bf[TN], af[TM];
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(As + pixoff[tn] + tapoff + ch * CHUNK_BYTES);
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) af[tm] = *reinterpret_cast<const uint4*>(wt + tm * 16 * RS + ch * CHUNK_BYTES);
+                for (int tm = 0; tm < TM; ++tm) af[tm] = *reinterpret_cast<const uint4*>(wt + ((aoff + tm * 2048) ^ (ch * 64)));
 #pragma unroll
                 for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < TN; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
             }
-            dy = ndy; dx = ndx;
-            buf ^= 1;
+            if (++dx == KW) { dx = 0; ++dy; }
+            if (++cslot == NSW) cslot = 0;
         }
     }
+    wait_vm_lgkm0<0>();                                   // the two slabs issued past the end must land before the LDS is released
 
     // ---- epilogue: bias, store, GroupNorm partial statistics --------------------------------------
     const int st_cpg = P.out_stats ? P.Cout / P.out_groups : 4;
@@ -418,34 +427,31 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     if (tid < 128) chs[tid] = 0.f;
 
     // per-thread staging pieces (constant over tiles): halo position, channel piece, LDS byte offset
-    int piy[NU], pix_[NU], ploff[NU], pch[NU];
+    // (register budget: 256 at 2 waves per SIMD and the prologue forms sit on it -- the halo row / column share one register, the
+    // channel piece is the same for every piece of a thread since 512 % PPR == 0)
+    static_assert(512 % PPR == 0, "pieces of a thread share their channel piece");
+    int pyx[NU], ploff[NU];                           // (halo row << 5) | halo column; row 100 = not a piece: never in range
+    const int pch0 = (tid % PPR) * PCH;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int i = tid + 512 * u;
         const int hp = min(i / PPR, C64_HALO - 1), pc = i % PPR;
-        piy[u] = (i < NPIECE) ? hp / 18 : -100;       // -100: never in range
-        pix_[u] = hp % 18;
-        pch[u] = pc * PCH;
+        pyx[u] = (((i < NPIECE) ? hp / 18 : 100) << 5) | (hp % 18);
         ploff[u] = IN16 ? swz(hp, pc) : (swz(hp, pc >> 1) + 8 * (pc & 1));
     }
     auto decode = [&](int t, int& f, int& ty, int& tx) { f = t / tiles_pf; const int r = t - f * tiles_pf; ty = r / tiles_x; tx = r - ty * tiles_x; };
 
     u32x4 sreg[NU];
     unsigned okmask = 0;
-    // prologue coefficients of THIS thread's channels: every piece of a thread covers the same PCH channels (512 % PPR == 0), so they
-    // live in registers and are re-read from the LDS table only when the sample changes (r01: 16 LDS reads per piece)
-    float ca[PCH], cd[PCH];
-#pragma unroll
-    for (int k = 0; k < PCH; ++k) { ca[k] = 0.f; cd[k] = 0.f; }
     auto stage_load = [&](int t) {
         int f, ty, tx; decode(t, f, ty, tx);
         okmask = 0;
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
-            const int gy = ty * 16 - 1 + piy[u], gx = tx * 16 - 1 + pix_[u];
+            const int gy = ty * 16 - 1 + (pyx[u] >> 5), gx = tx * 16 - 1 + (pyx[u] & 31);
             const bool ok = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
             okmask |= ok ? (1u << u) : 0u;
-            const unsigned off = ok ? (unsigned)(((f * P.H + gy) * P.W + gx) * 64 + pch[u]) * (IN16 ? 2u : 4u) : OOB;
+            const unsigned off = ok ? (unsigned)(((f * P.H + gy) * P.W + gx) * 64 + pch0) * (IN16 ? 2u : 4u) : OOB;
             sreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
         }
     };
@@ -454,11 +460,17 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             if (u < u0 || u >= u1) continue;
-            if (piy[u] < 0) continue;
+            if ((pyx[u] >> 5) > 17) continue;
             const bool ok = (okmask >> u) & 1u;
             if (IN16) {
                 u32x4 v = sreg[u];
                 if (PRO) {
+                    float ca[PCH], cd[PCH];                           // (LDS broadcast-free reads: 4 x 16 B per piece; registers spilled, r02)
+#pragma unroll
+                    for (int k = 0; k < PCH; k += 4) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(coefA + pch0 + k), d4 = *reinterpret_cast<const float4*>(coefD + pch0 + k);
+                        ca[k] = a4.x; ca[k + 1] = a4.y; ca[k + 2] = a4.z; ca[k + 3] = a4.w; cd[k] = d4.x; cd[k + 1] = d4.y; cd[k + 2] = d4.z; cd[k + 3] = d4.w;
+                    }
                     const unsigned w4[4] = {v.x, v.y, v.z, v.w};
                     unsigned o4[4];
 #pragma unroll
@@ -473,6 +485,8 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             } else {
                 float4 f = make_float4(__uint_as_float(sreg[u].x), __uint_as_float(sreg[u].y), __uint_as_float(sreg[u].z), __uint_as_float(sreg[u].w));
                 if (PRO) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(coefA + pch0), d4 = *reinterpret_cast<const float4*>(coefD + pch0);
+                    const float ca[4] = {a4.x, a4.y, a4.z, a4.w}, cd[4] = {d4.x, d4.y, d4.z, d4.w};
                     f.x = ok ? silu_f(fmaf(f.x, ca[0], cd[0])) : 0.f; f.y = ok ? silu_f(fmaf(f.y, ca[1], cd[1])) : 0.f;
                     f.z = ok ? silu_f(fmaf(f.z, ca[2], cd[2])) : 0.f; f.w = ok ? silu_f(fmaf(f.w, ca[3], cd[3])) : 0.f;
                 }
@@ -494,8 +508,6 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             coefD[tid] = (P.beta[tid] - m * rsd * P.gamma[tid]) * sc + sh;
         }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < PCH; ++k) { ca[k] = coefA[pch[0] + k]; cd[k] = coefD[pch[0] + k]; }
     };
     // flush the register partial sums of sample b into out_stats (all threads call)
     f32x4 ssum[4], ssq[4];
@@ -1017,7 +1029,7 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     a.m_ihiw = magic(IH * IW); a.m_iw = magic(IW); a.m_phpw = magic(a.PH * a.PW); a.m_pw = magic(a.PW);
     if (IW < 2 || a.PW < 2) return hipErrorInvalidValue;
     size_t lds = 2 * BC * 4 + ((HPX * 4 + 15) / 16) * 16 + (a.pro ? (2 * a.CinPad * 4 + 64 * 4) : 0)
-               + (size_t)HPX * ROW_STRIDE + 2 * (size_t)BC * ROW_STRIDE;
+               + (size_t)HPX * ROW_STRIDE + 3 * (size_t)BC * 128;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((a.NF / a.NP) * a.tiles_y * a.tiles_x, (a.Cout + BC - 1) / BC, a.kind ? 4 : 1);
     const bool in16 = mode == MODE_BF16 && a.x0_bf16 && (!a.C1 || a.x1_bf16) && (a.C0 % 8 == 0) && (a.C1 % 8 == 0);

@@ -27,6 +27,7 @@
 // applied to the SOURCE address of each lane and again when reading (cdna_hip_programming.md rule 21).
 #include "vdx_common.h"
 #include "vdx_internal.h"
+#include "vdx_glds.h"
 #include <type_traits>
 
 namespace vdx {
@@ -35,36 +36,12 @@ namespace {
 
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[4];      // source of every out-of-image halo piece
 
-// 16-byte LDS-DMA: lane l's 16 bytes at `src` land at LDS byte address lds_wave_base + 16 l (wave-uniform base in M0).
-// Inline asm on purpose: hipcc's wait-count pass puts an s_waitcnt vmcnt(0) in front of the next ds_read after the BUILTIN form
-// (it cannot prove that the LDS-DMA destination and the read do not alias), which drains the ring every tap; the asm form is
-// invisible to that pass and every wait on these loads is the hand-counted one at the tap's sync (cdna_hip_programming.md 5.7).
-__device__ __forceinline__ void glds16(const void* src, unsigned lds_wave_base) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(lds_wave_base) : "memory");
-}
-__device__ __forceinline__ unsigned lds_addr(const char* p) {
-    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
-}
-
 // byte offset of 16-byte chunk (4 ks + q) of LDS row `row` whose swizzle key is `key` (chunk k sits at position k ^ (key & 7)), for
 // ks = 0; ks = 1 is this ^ 64
 __device__ __forceinline__ int frag_off(int row, int key, int q) { return row * 128 + (((q ^ (key & 3)) | (key & 4)) << 4); }
 
 constexpr int WS_SLAB = 128 * 128;            // one (tap, K chunk) weight slab: 128 couts x 64 cin bf16
 constexpr int WS_STORES = 16;                 // global stores per wave in the tile epilogue (4 x 4 MFMA tiles, unconditional)
-
-template <int N> __device__ __forceinline__ void wait_vm_lgkm0() {
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(N) : "memory");
-}
-// the per-tap sync: LDS-DMA count only.  No lgkmcnt: when a wave reaches the barrier every LDS access that could conflict with what
-// the barrier releases has completed (LDS operations of a wave complete in order, and the last MFMAs consumed the last reads of the
-// slab / buffer being retired; the transform's writes precede those reads); only the next tap's prefetched fragment reads are still in
-// flight, and they read data nobody overwrites.  Their latency then overlaps the barrier wait instead of preceding it.
-template <int N> __device__ __forceinline__ void wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
-}
 
 }  // namespace
 
