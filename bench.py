@@ -83,6 +83,8 @@ def conv_symbol(i):
         return 'vdx::conv128x64p_kernel'
     if i.kernel == 3:
         return f'vdx::conv3x3_ws_kernel<{i.geo}, {tf(i.pro)}>'
+    if i.kernel == 4:
+        return f'vdx::conv4x4_ws_kernel<{i.geo}, {2 if i.kind == 1 else 1}>'
     return f'vdx::conv_igemm_kernel<{i.mode}, {i.bc}, 2, {i.nw}, {i.inf}>'
 
 

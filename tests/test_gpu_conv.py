@@ -230,3 +230,40 @@ def test_weight_streaming_conv(case, y_bf16):
         ref2 = R.conv_1kk(_bf16r(R.silu(h).float()).double(), _bf16r(kern2).double(), None)
         r2 = _rel(y2.float().cpu().double(), ref2)
         assert r2 < 5e-3, (use_ss, r2)
+
+
+WS4_CASES = [
+    # kind (0 = Downsample 4x4 / stride 2, 1 = Upsample ConvTranspose), B, F, S_in, C, Cout   (bf16 tensors; >= 128 work items)
+    (0, 8, 16, 32, 128, 128),          # level-1 Downsample: 32 -> 16, whole 16 x 16 output frames, 2 K chunks per parity plane
+    (0, 16, 16, 16, 256, 256),         # level-2 Downsample: 16 -> 8, four 8 x 8 output frames per tile, two output-channel tiles
+    (0, 52, 10, 16, 64, 128),          # one K chunk per plane, F = 10: 130 tiles over 128 ranges (ragged)
+    (1, 8, 16, 8, 256, 256),           # level-3 -> 2 Upsample: 8 -> 16, four input frames per tile x 4 phases
+    (1, 4, 16, 16, 128, 128),          # level-2 -> 1 Upsample: 16 -> 32
+    (1, 11, 12, 8, 64, 128),           # 33 input tiles x 4 phases over 128 ranges (ragged, ranges of whole phase groups)
+]
+
+
+@pytest.mark.parametrize('case', WS4_CASES)
+@pytest.mark.parametrize('y_bf16', [True, False])
+def test_weight_streaming_resampling_conv(case, y_bf16):
+    """conv4x4_ws_kernel (conv_ws.hip): Downsample / Upsample of the wide levels on the weight-streaming machinery (parity planes /
+    output phases of 2 x 2 taps); reference utils.py:103-125 through the oracle's conv_1kk(stride 2) / conv_transpose_144."""
+    from video_diffusion_nnx_amd import ops
+    dev = torch.device('cuda:0')
+    kind, B, Fr, S, C, Cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Fr, S, S, C, generator=g)
+    kern = torch.randn(1, 4, 4, C, Cout, generator=g) / (8 * C) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    pw = ops.pack_conv_weights(kern.to(dev), 'bf16')
+    xd = x.to(dev).to(torch.bfloat16)
+    if kind == 1:
+        y = ops.conv_forward(xd, pw, Cout, mode='bf16', bias=bias.to(dev), kind=1, k=4, y_bf16=y_bf16)
+        ref = R.conv_transpose_144(_bf16r(x).double(), _bf16r(kern).double(), bias.double())
+    else:
+        y = ops.conv_forward(xd, pw, Cout, mode='bf16', bias=bias.to(dev), k=4, stride=2, y_bf16=y_bf16)
+        ref = R.conv_1kk(_bf16r(x).double(), _bf16r(kern).double(), bias.double(), stride=2)
+    torch.cuda.synchronize()
+    assert tuple(y.shape) == tuple(ref.shape)
+    r = _rel(y.float().cpu().double(), ref)
+    assert r < (4e-3 if y_bf16 else 2e-6), r

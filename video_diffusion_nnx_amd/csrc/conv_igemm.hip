@@ -998,6 +998,10 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
         HookScope hs(mode, a, st, 3, 0, 0, 0, conv3x3_ws_geo(a));
         return launch_conv3x3_ws(a, st);
     }
+    if (conv4x4_ws_eligible(mode, a)) {                                      // 4x4 resampling convs of the wide levels
+        HookScope hs(mode, a, st, 4, 0, 0, 0, a.kind == 1 ? a.H : a.H / 2);
+        return launch_conv4x4_ws(a, st);
+    }
     {   // persistent specialisation for the level-0 shape (see conv64p_kernel)
         const int use64p = 1;
         const long tiles = (long)a.NF * (a.H / 16) * (a.W / 16);

@@ -400,6 +400,219 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
     wait_vm_lgkm0<0>();                                   // the prefetches issued past the end must land before the LDS is released
 }
 
+// ---- the 4x4 / stride-2 resampling convs on the same machinery (round 2) ------------------------------------------------------
+// Downsample (reference utils.py:115-125: 4x4, stride 2, SAME) and Upsample (utils.py:103-113: ConvTranspose 4x4, stride 2) of the wide
+// levels ran on the generic kernel at 0.14-0.30 of the MFMA peak (16 taps of 16 MFMAs per wave between two barriers).  Both are a
+// 2 x 2-tap convolution per (phase, 64-channel chunk) on a 256-pixel whole-frame tile, so they reuse the weight ring, the double-buffered
+// LDS-DMA input tile with its zero row, the counted waits and the 64 x 64 wave tiles of conv3x3_ws_kernel:
+//   KIND 1, Downsample: GEO = OUTPUT frame size.  Input row 2y + i - 1 = 2(y + a) + p: the input splits in four parity planes (py, px),
+//     each a frame of the OUTPUT size; plane p uses the taps a in {-1, 0} (p = 1) or {0, 1} (p = 0) per axis.  K chunk = (plane, 64
+//     channels): the tile is GATHERED from the plane's pixels (16-byte pieces stay contiguous), 4 taps (dy, dx) in {ey, ey+1} x {ex, ex+1}
+//     of the 3 x 3 fragment addressing with ey = 1 - py, packed tap index (1 - py + 2 ky) * 4 + (1 - px + 2 kx).
+//   KIND 2, Upsample: GEO = INPUT frame size.  Output phase (ry, rx) of pixel (y, x) = sum over 2 x 2 taps of input (y + ry - 1 + ky, ...):
+//     the four phases of a tile are four consecutive "virtual tiles" on the same input, taps {ry, ry+1} x {rx, rx+1}, packed tap index
+//     (2 ky + ry) * 4 + (2 kx + rx), outputs scattered to (2y + ry, 2x + rx).
+// No prologue, no statistics (the reference's resampling convs have neither); bias in the epilogue.
+template <int GEO, int KIND>
+__global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, const int tiles_per_range, const int total_vtiles, const int nct) {
+    using M = Mma<MODE_BF16>;
+    using G = WsGeo<GEO>;
+    static_assert(G::WF && (KIND == 1 || KIND == 2), "whole-frame geometries only");
+    constexpr int S = G::S, NP = G::NP, HPX = G::HPX, NPIECE = G::NPIECE, NU = G::NU, NUMIN = G::NUMIN, HBUF = G::HBUF;
+    constexpr int NS = WS_NS, WIN = 2;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;                                    // [NS][128 rows][128 B]
+    char* halo = ring + NS * WS_SLAB;                     // [2][HPX rows][128 B]
+    float* biasl = reinterpret_cast<float*>(halo + 2 * HBUF);
+    const unsigned ring_a = lds_addr(ring), halo_a = lds_addr(halo);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int wc = wave & 1, wpx = wave >> 1;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int j = slot % nct;
+    const int range = (slot / nct) * 8 + xcd;
+    const int t0 = range * tiles_per_range, t1 = min(t0 + tiles_per_range, total_vtiles);
+    if (t0 >= t1) return;
+    const int C = P.C0;
+    const int ncc = C >> 6;                               // 64-channel chunks of the input
+    const int nchunks = KIND == 1 ? 4 * ncc : ncc;        // K chunks per (virtual) tile
+
+    unsigned wsrc[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int i2 = (v * 8 + wave) * 64 + lane, row = i2 >> 3, pos = i2 & 7;
+        wsrc[v] = (unsigned)((j * 128 + row) * P.CinPad) * 2u + (unsigned)((pos ^ (row & 7)) << 4);
+    }
+    const size_t tap_stride = (size_t)P.Cout * P.CinPad * 2;
+    const char* wbase = reinterpret_cast<const char*>(P.wp);
+    auto piece = [&](int u, int l, int& row, int& chunk) -> bool {
+        const int i = (u * 8 + wave) * 64 + l;
+        row = i >> 3;
+        chunk = (i & 7) ^ (row & 7);
+        return i < NPIECE;
+    };
+    auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+    const char* const zero_page = reinterpret_cast<const char*>(g_zero_page);
+    constexpr int DYB = S * 128;
+    const int halo_o = NS * WS_SLAB;
+    const int aoff = frag_off(wc * 64 + r, r, q);
+    int b3[4][3], zs[3], opix[4];
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+        const int p = wpx * 64 + tn * 16 + r;
+        if (KIND == 1) opix[tn] = p;
+        else { const int fl = p / (S * S), y = (p / S) % S, x = p % S; opix[tn] = (fl * 2 * S + 2 * y) * 2 * S + 2 * x; }      // phase (0, 0) of the pixel in the tile's output frames
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) b3[tn][dx] = halo_o + frag_off(p - S - 1 + dx, p - 1 + dx, q);
+    }
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) zs[dy] = halo_o + 256 * 128 + (q << 4) - dy * DYB;
+    auto tap_valid = [&](int tn, int dy, int dx) -> bool {
+        const int p = wpx * 64 + tn * 16 + r, y = (p / S) % S + dy - 1, x = p % S + dx - 1;
+        return y >= 0 && y < S && x >= 0 && x < S;
+    };
+    if (tid < 128) biasl[tid] = P.bias ? P.bias[j * 128 + tid] : 0.f;
+
+    // weight prefetch cursor: (phase of the virtual tile (KIND 2), K chunk, tap) in consumption order; the stream repeats per tile (KIND 1) / per 4 virtual tiles
+    int pph = t0 & 3, pcc = 0, ptap = 0, pslot = 0;
+    auto issue_w = [&]() {
+        const int ky = ptap >> 1, kx = ptap & 1;
+        int widx, kofs;
+        if (KIND == 1) { const int plane = pcc / ncc, cch = pcc - plane * ncc; widx = (1 - (plane >> 1) + 2 * ky) * 4 + (1 - (plane & 1) + 2 * kx); kofs = cch << 7; }
+        else { widx = (2 * ky + (pph >> 1)) * 4 + (2 * kx + (pph & 1)); kofs = pcc << 7; }
+        const char* src = wbase + (size_t)widx * tap_stride + (size_t)kofs;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_a + pslot * WS_SLAB + wave * 1024);
+        glds16(src + wsrc[0], dst);
+        glds16(src + wsrc[1], dst + 8 * 1024);
+        if (++ptap == 4) { ptap = 0; if (++pcc == nchunks) { pcc = 0; pph = (pph + 1) & 3; } }
+        if (++pslot == NS) pslot = 0;
+    };
+    auto issue_halo = [&](int vt, int cc, int buf) {
+        const char* xb = reinterpret_cast<const char*>(P.x0);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(halo_a + buf * HBUF + wave * 1024);
+        const int l = opaque_lane();
+        const int plane = KIND == 1 ? cc / ncc : 0, cch = KIND == 1 ? cc - plane * ncc : cc;
+        const int py = plane >> 1, px = plane & 1;
+        const int tile = KIND == 1 ? vt : (vt >> 2);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            int row, ch;
+            if (piece(u, l, row, ch)) {
+                const bool ok = row < 256;
+                unsigned pix;
+                if (KIND == 1) {
+                    const int fl = row / (S * S), y = (row / S) % S, x = row % S;
+                    pix = (unsigned)(((tile * NP + fl) * 2 * S + 2 * y + py) * 2 * S + 2 * x + px);
+                } else pix = (unsigned)tile * 256u + row;
+                const unsigned off = (pix * C + (cch << 6) + (ch << 3)) * 2u;
+                const void* src = ok ? static_cast<const void*>(xb + off) : static_cast<const void*>(zero_page);
+                glds16(src, dst + u * 8 * 1024);
+            }
+        }
+    };
+    auto ldA1 = [&](int sl, int tm, int ks) -> uint4 {
+        return *reinterpret_cast<const uint4*>(ring + sl * WS_SLAB + ((aoff + tm * 2048) ^ (ks * 64)));
+    };
+    auto flip_buffers = [&](int to_buf1) {
+        const int d = to_buf1 ? HBUF : -HBUF;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) b3[tn][dx] += d;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) zs[dy] += d;
+    };
+
+    issue_halo(t0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NS - 1; ++k) issue_w();
+    wait_vm_lgkm0<0>();
+    __builtin_amdgcn_s_barrier();
+
+    int cslot = 0, hbuf = 0;
+    f32x4 acc[4][4];
+    // one K chunk = 4 taps (EY + ky, EX + kx) on input buffer hbuf; (tnext, ccnext) = the buffer to fetch meanwhile (conv3x3_ws_kernel's
+    // schedule: the pieces issued at tap 0 are older than the slab tap 2's sync waits for)
+    auto run_chunk = [&](auto after_epi, auto ey_, auto ex_, int tnext, int ccnext) {
+        constexpr int EPI = decltype(after_epi)::value ? WS_STORES : 0;
+        constexpr int EY = decltype(ey_)::value, EX = decltype(ex_)::value;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            constexpr int dummy = 0; (void)dummy;
+            const int dy = EY + (k >> 1), dx = EX + (k & 1);                 // (constants after unrolling)
+            if (k == 0) wait_vm<WIN + EPI>();
+            else if (k == 1) wait_vm<WIN + NUMIN + EPI>();
+            else wait_vm<WIN>();
+            __builtin_amdgcn_s_barrier();
+            if (k == 0) issue_halo(tnext, ccnext, hbuf ^ 1);
+            issue_w();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint4 b[4];
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    int a = b3[tn][dx];
+                    a = tap_valid(tn, dy, dx) ? a : zs[dy];
+                    b[tn] = *reinterpret_cast<const uint4*>(smem + ((a ^ (ks * 64)) + dy * DYB));
+                }
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+                    const uint4 a = ldA1(cslot, tm, ks);
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) M::mma(acc[tm][tn], a, b[tn]);
+                }
+            }
+            if (k == 3) flip_buffers(hbuf ^ 1);
+            cslot = (cslot + 1 == NS) ? 0 : cslot + 1;
+        }
+        hbuf ^= 1;
+    };
+    auto run_parity = [&](auto after_epi, int ey, int ex, int tnext, int ccnext) {
+        using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
+        if (ey == 0) { if (ex == 0) run_chunk(after_epi, T0{}, T0{}, tnext, ccnext); else run_chunk(after_epi, T0{}, T1{}, tnext, ccnext); }
+        else { if (ex == 0) run_chunk(after_epi, T1{}, T0{}, tnext, ccnext); else run_chunk(after_epi, T1{}, T1{}, tnext, ccnext); }
+    };
+
+    bool after_epilogue = false;
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int cc = 0; cc < nchunks; ++cc) {
+            const bool last = (cc + 1 == nchunks);
+            const int tnext = last ? (t + 1 < t1 ? t + 1 : t) : t, ccnext = last ? 0 : cc + 1;
+            int ey, ex;
+            if (KIND == 1) { const int plane = cc / ncc; ey = 1 - (plane >> 1); ex = 1 - (plane & 1); }
+            else { ey = (t & 3) >> 1; ex = t & 1; }
+            if (after_epilogue) run_parity(std::true_type{}, ey, ex, tnext, ccnext);
+            else run_parity(std::false_type{}, ey, ex, tnext, ccnext);
+            after_epilogue = false;
+        }
+        {   // epilogue of (virtual) tile t: + bias, store
+            size_t tile_pix;
+            if (KIND == 1) tile_pix = (size_t)t * 256;
+            else tile_pix = (size_t)(t >> 2) * 1024 + (size_t)(((t & 3) >> 1) * 2 * S + (t & 1));     // 4 output pixels per input pixel; phase offset
+            const int cobase = j * 128 + wc * 64 + 4 * q;
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) {
+                const float4 bs = *reinterpret_cast<const float4*>(biasl + wc * 64 + tm * 16 + 4 * q);
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    const float4 v = make_float4(acc[tm][tn][0] + bs.x, acc[tm][tn][1] + bs.y, acc[tm][tn][2] + bs.z, acc[tm][tn][3] + bs.w);
+                    const size_t e = (tile_pix + opix[tn]) * P.Cout + cobase + tm * 16;
+                    if (P.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.y) + e * 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+                    else *reinterpret_cast<float4*>(P.y + e) = v;
+                }
+            }
+            after_epilogue = true;
+        }
+    }
+    wait_vm_lgkm0<0>();
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------------------
 
 static int ws_geo(const ConvArgs& a) {                    // 0: 16 x 16 tiles, 8 / 16: whole frames, -1: not served
@@ -410,6 +623,53 @@ static int ws_geo(const ConvArgs& a) {                    // 0: 16 x 16 tiles, 8
 }
 
 int conv3x3_ws_geo(const ConvArgs& a) { return ws_geo(a); }
+
+// frame size of the 256-pixel whole-frame tiles of the 4x4 resampling kernel (output frames of Downsample, input frames of Upsample), or 0
+static int ws4_geo(const ConvArgs& a) {
+    const bool down = a.kind == 0 && a.kh == 4 && a.kw == 4 && a.stride == 2, up = a.kind == 1;
+    if (!down && !up) return 0;
+    const int s = down ? a.H / 2 : a.H;
+    if (a.H != a.W || (down && (a.H % 2))) return 0;
+    if (s == 16) return 16;
+    if (s == 8 && a.NF % 4 == 0) return 8;
+    return 0;
+}
+
+bool conv4x4_ws_eligible(int mode, const ConvArgs& a) {
+    if (mode != MODE_BF16 || a.res || a.pro || a.out_stats || a.C1 || !a.x0_bf16) return false;
+    const int geo = ws4_geo(a);
+    if (!geo) return false;
+    if (a.C0 % 64 || a.Cout % 128 || a.CinPad != a.C0) return false;
+    const int nct = a.Cout / 128;
+    if (nct != 1 && nct != 2 && nct != 4 && nct != 8) return false;
+    if (a.wrows != a.Cout || a.wrow0 != 0) return false;
+    const long vtiles = (long)a.NF * geo * geo / 256 * (a.kind == 1 ? 4 : 1);
+    if (vtiles * nct < 128) return false;
+    if ((size_t)a.NF * a.H * a.W * (size_t)a.C0 * 2 >= 0xFFFF0000ull || (size_t)a.NF * 4 * geo * geo >= 0x7FFFFFFFull) return false;
+    return true;
+}
+
+hipError_t launch_conv4x4_ws(const ConvArgs& a, hipStream_t st) {
+    const int geo = ws4_geo(a), nct = a.Cout / 128, up = a.kind == 1;
+    const int total = (int)((long)a.NF * geo * geo / 256) * (up ? 4 : 1);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const int unit = 8 * nct;
+    int grid = std::max(unit, cus / unit * unit);
+    grid = std::min(grid, (total * nct + unit - 1) / unit * unit);
+    const int nranges = grid / nct;
+    int tpr = (total + nranges - 1) / nranges;
+    if (up) tpr = (tpr + 3) / 4 * 4;                      // a range = whole groups of 4 phases (the weight stream's phase follows t & 3)
+    const size_t lds = (size_t)WS_NS * WS_SLAB + 2 * (size_t)257 * 128 + 512;
+    auto go = [&](auto kfn) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a, tpr, total, nct);
+        return hipGetLastError();
+    };
+    if (geo == 8) return up ? go(conv4x4_ws_kernel<8, 2>) : go(conv4x4_ws_kernel<8, 1>);
+    return up ? go(conv4x4_ws_kernel<16, 2>) : go(conv4x4_ws_kernel<16, 1>);
+}
 
 bool conv3x3_ws_eligible(int mode, const ConvArgs& a) {
     if (mode != MODE_BF16 || a.kind != 0 || a.kh != 3 || a.kw != 3 || a.stride != 1 || a.res) return false;

@@ -217,7 +217,9 @@ int conv_cin_pad(int mode, int Cin);
 hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, int Cin, int Cout, hipStream_t st);
 hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st);
 void set_conv_launch_hook(vdx_conv_launch_hook hook, void* user);
-int conv3x3_ws_geo(const ConvArgs& a);       // 0 / 8 / 16: the GEO template argument launch_conv3x3_ws will use
+int conv3x3_ws_geo(const ConvArgs& a);
+bool conv4x4_ws_eligible(int mode, const ConvArgs& a);     // Downsample / Upsample of the wide levels on the weight-streaming machinery
+hipError_t launch_conv4x4_ws(const ConvArgs& a, hipStream_t st);       // 0 / 8 / 16: the GEO template argument launch_conv3x3_ws will use
 // persistent weight-streaming 3x3 kernel for Cout % 128 == 0 with bf16 tensors (conv_ws.hip); `a` geometry-completed by launch_conv
 bool conv3x3_ws_eligible(int mode, const ConvArgs& a);
 hipError_t launch_conv3x3_ws(const ConvArgs& a, hipStream_t st);
