@@ -84,7 +84,7 @@ def conv_symbol(i):
     if i.kernel == 3:
         return f'vdx::conv3x3_ws_kernel<{i.geo}, {tf(i.pro)}>'
     if i.kernel == 4:
-        return f'vdx::conv4x4_ws_kernel<{i.geo}, {2 if i.kind == 1 else 1}>'
+        return f'vdx::conv4x4_ws_kernel<{i.geo}, {2 if i.kind == 1 else 1}, {i.bc}>'
     return f'vdx::conv_igemm_kernel<{i.mode}, {i.bc}, 2, {i.nw}, {i.inf}>'
 
 

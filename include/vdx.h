@@ -92,7 +92,7 @@ int vdx_conv_forward(int mode, const vdx_conv_desc* d, void* stream);
 typedef struct {
     int kernel;                   /* 0 conv_igemm_kernel, 1 conv64p_kernel, 2 conv128x64p_kernel, 3 conv3x3_ws_kernel, 4 conv4x4_ws_kernel */
     int mode, bc, nw, inf;        /* conv_igemm template arguments <mode, BC, 2, NW, INF> */
-    int geo, pro;                 /* conv3x3_ws <GEO, PRO>; conv4x4_ws <GEO, 1 + kind>; conv64p <IN16, PRO, OUT16> uses x_bf16 / pro / y_bf16 */
+    int geo, pro;                 /* conv3x3_ws <GEO, PRO>; conv4x4_ws <GEO, 1 + kind, bc>; conv64p <IN16, PRO, OUT16> uses x_bf16 / pro / y_bf16 */
     int x_bf16, y_bf16;
     int cin, cout, h, w, nf, taps, kind, stride;     /* nf = batch * frames; kind 1 = ConvTranspose (4 phases, one launch) */
 } vdx_conv_launch_info;

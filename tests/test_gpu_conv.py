@@ -240,6 +240,10 @@ WS4_CASES = [
     (1, 8, 16, 8, 256, 256),           # level-3 -> 2 Upsample: 8 -> 16, four input frames per tile x 4 phases
     (1, 4, 16, 16, 128, 128),          # level-2 -> 1 Upsample: 16 -> 32
     (1, 11, 12, 8, 64, 128),           # 33 input tiles x 4 phases over 128 ranges (ragged, ranges of whole phase groups)
+    (0, 4, 16, 64, 64, 64),            # level-0 Downsample: 64 -> 32, bands of 8 x 32 output pixels, 64-channel output tile
+    (1, 2, 16, 32, 64, 64),            # level-1 -> 0 Upsample: 32 -> 64, bands of 8 x 32 input pixels x 4 phases
+    (0, 3, 12, 64, 128, 128),          # bands with a 128-channel output tile, 2 K chunks per plane, 144 tiles (ragged)
+    (1, 8, 16, 16, 128, 64),           # whole 16 x 16 frames with a 64-channel output tile
 ]
 
 

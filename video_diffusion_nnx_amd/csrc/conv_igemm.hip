@@ -999,7 +999,7 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
         return launch_conv3x3_ws(a, st);
     }
     if (conv4x4_ws_eligible(mode, a)) {                                      // 4x4 resampling convs of the wide levels
-        HookScope hs(mode, a, st, 4, 0, 0, 0, a.kind == 1 ? a.H : a.H / 2);
+        HookScope hs(mode, a, st, 4, a.Cout == 64 ? 64 : 128, 0, 0, a.kind == 1 ? a.H : a.H / 2);
         return launch_conv4x4_ws(a, st);
     }
     {   // persistent specialisation for the level-0 shape (see conv64p_kernel)

@@ -413,23 +413,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
 //     the four phases of a tile are four consecutive "virtual tiles" on the same input, taps {ry, ry+1} x {rx, rx+1}, packed tap index
 //     (2 ky + ry) * 4 + (2 kx + rx), outputs scattered to (2y + ry, 2x + rx).
 // No prologue, no statistics (the reference's resampling convs have neither); bias in the epilogue.
-template <int GEO, int KIND>
+// GEO 8 / 16: whole frames of that size (the coarse side of the resampling); GEO 32: BANDS of 8 rows x 32 columns of a 32 x 32 frame
+// with one halo row above and below (out-of-frame rows read the zero page, out-of-frame COLUMNS select the zero row) -- the two
+// resampling convs of the widest level.  BCO = output channels per workgroup: 128 (wave tile 64 couts x 64 pixels) or 64 (every wave
+// takes all 64 couts of 32 pixels; 8 KB slabs, one LDS-DMA per wave per slab).
+template <int GEO, int KIND, int BCO>
 __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, const int tiles_per_range, const int total_vtiles, const int nct) {
     using M = Mma<MODE_BF16>;
-    using G = WsGeo<GEO>;
-    static_assert(G::WF && (KIND == 1 || KIND == 2), "whole-frame geometries only");
-    constexpr int S = G::S, NP = G::NP, HPX = G::HPX, NPIECE = G::NPIECE, NU = G::NU, NUMIN = G::NUMIN, HBUF = G::HBUF;
-    constexpr int NS = WS_NS, WIN = 2;
+    static_assert((GEO == 8 || GEO == 16 || GEO == 32) && (KIND == 1 || KIND == 2) && (BCO == 64 || BCO == 128), "geometry");
+    constexpr bool BAND = GEO == 32;
+    constexpr int S = GEO;                                 // frame size of the tile's pixel grid
+    constexpr int NP = BAND ? 1 : 256 / (S * S);           // frames per tile (whole-frame geometries)
+    constexpr int ZROW = BAND ? 320 : 256;                 // the zero row; BAND: rows 0..319 = band rows -1..8 x 32 columns
+    constexpr int HPX = ZROW + 1, NPIECE = HPX * 8, NU = (NPIECE + 511) / 512, NUMIN = NPIECE / 512, HBUF = HPX * 128;
+    constexpr int NS = WS_NS;
+    constexpr int WIN = BCO / 64;                          // LDS-DMA instructions per wave per slab
+    constexpr int SLAB = BCO * 128;
+    constexpr int TN = BCO == 128 ? 4 : 2;                 // 16-pixel tiles per wave
+    constexpr int STORES = 4 * TN;                         // global stores per wave in the tile epilogue
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;                                    // [NS][128 rows][128 B]
-    char* halo = ring + NS * WS_SLAB;                     // [2][HPX rows][128 B]
+    char* halo = ring + NS * SLAB;                        // [2][HPX rows][128 B]
     float* biasl = reinterpret_cast<float*>(halo + 2 * HBUF);
     const unsigned ring_a = lds_addr(ring), halo_a = lds_addr(halo);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int wc = wave & 1, wpx = wave >> 1;
+    const int wc = BCO == 128 ? (wave & 1) : 0, wpx = BCO == 128 ? (wave >> 1) : wave;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int j = slot % nct;
     const int range = (slot / nct) * 8 + xcd;
@@ -439,11 +450,11 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
     const int ncc = C >> 6;                               // 64-channel chunks of the input
     const int nchunks = KIND == 1 ? 4 * ncc : ncc;        // K chunks per (virtual) tile
 
-    unsigned wsrc[2];
+    unsigned wsrc[WIN];
 #pragma unroll
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < WIN; ++v) {
         const int i2 = (v * 8 + wave) * 64 + lane, row = i2 >> 3, pos = i2 & 7;
-        wsrc[v] = (unsigned)((j * 128 + row) * P.CinPad) * 2u + (unsigned)((pos ^ (row & 7)) << 4);
+        wsrc[v] = (unsigned)((j * BCO + row) * P.CinPad) * 2u + (unsigned)((pos ^ (row & 7)) << 4);
     }
     const size_t tap_stride = (size_t)P.Cout * P.CinPad * 2;
     const char* wbase = reinterpret_cast<const char*>(P.wp);
@@ -456,24 +467,25 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
     auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
     const char* const zero_page = reinterpret_cast<const char*>(g_zero_page);
     constexpr int DYB = S * 128;
-    const int halo_o = NS * WS_SLAB;
+    const int halo_o = NS * SLAB;
     const int aoff = frag_off(wc * 64 + r, r, q);
-    int b3[4][3], zs[3], opix[4];
+    int b3[TN][3], zs[3], opix[TN];
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-        const int p = wpx * 64 + tn * 16 + r;
+    for (int tn = 0; tn < TN; ++tn) {
+        const int p = wpx * (TN * 16) + tn * 16 + r;       // pixel of the tile: (frame, y, x) row-major, or (band row, x)
         if (KIND == 1) opix[tn] = p;
-        else { const int fl = p / (S * S), y = (p / S) % S, x = p % S; opix[tn] = (fl * 2 * S + 2 * y) * 2 * S + 2 * x; }      // phase (0, 0) of the pixel in the tile's output frames
+        else { const int fl = p / (S * S), y = (p / S) % S, x = p % S; opix[tn] = (fl * 2 * S + 2 * y) * 2 * S + 2 * x; }      // phase (0, 0) of the pixel in the tile's output rows
+        // LDS row of tap (dy, dx): whole frames p + (dy - 1) S + dx - 1; bands (halo row first) p + dy S + dx - 1.  S % 8 == 0: one key per dx
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) b3[tn][dx] = halo_o + frag_off(p - S - 1 + dx, p - 1 + dx, q);
+        for (int dx = 0; dx < 3; ++dx) b3[tn][dx] = halo_o + frag_off(p - (BAND ? 0 : S) - 1 + dx, p - 1 + dx, q);
     }
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) zs[dy] = halo_o + 256 * 128 + (q << 4) - dy * DYB;
+    for (int dy = 0; dy < 3; ++dy) zs[dy] = halo_o + ZROW * 128 + (q << 4) - dy * DYB;
     auto tap_valid = [&](int tn, int dy, int dx) -> bool {
-        const int p = wpx * 64 + tn * 16 + r, y = (p / S) % S + dy - 1, x = p % S + dx - 1;
-        return y >= 0 && y < S && x >= 0 && x < S;
+        const int p = wpx * (TN * 16) + tn * 16 + r, y = (p / S) % S + dy - 1, x = p % S + dx - 1;
+        return (BAND || (y >= 0 && y < S)) && x >= 0 && x < S;          // (bands: the halo rows hold the vertical neighbours or zeros)
     };
-    if (tid < 128) biasl[tid] = P.bias ? P.bias[j * 128 + tid] : 0.f;
+    if (tid < BCO) biasl[tid] = P.bias ? P.bias[j * BCO + tid] : 0.f;
 
     // weight prefetch cursor: (phase of the virtual tile (KIND 2), K chunk, tap) in consumption order; the stream repeats per tile (KIND 1) / per 4 virtual tiles
     int pph = t0 & 3, pcc = 0, ptap = 0, pslot = 0;
@@ -483,9 +495,9 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
         if (KIND == 1) { const int plane = pcc / ncc, cch = pcc - plane * ncc; widx = (1 - (plane >> 1) + 2 * ky) * 4 + (1 - (plane & 1) + 2 * kx); kofs = cch << 7; }
         else { widx = (2 * ky + (pph >> 1)) * 4 + (2 * kx + (pph & 1)); kofs = pcc << 7; }
         const char* src = wbase + (size_t)widx * tap_stride + (size_t)kofs;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_a + pslot * WS_SLAB + wave * 1024);
-        glds16(src + wsrc[0], dst);
-        glds16(src + wsrc[1], dst + 8 * 1024);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_a + pslot * SLAB + wave * 1024);
+#pragma unroll
+        for (int v = 0; v < WIN; ++v) glds16(src + wsrc[v], dst + v * 8 * 1024);
         if (++ptap == 4) { ptap = 0; if (++pcc == nchunks) { pcc = 0; pph = (pph + 1) & 3; } }
         if (++pslot == NS) pslot = 0;
     };
@@ -500,9 +512,13 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
         for (int u = 0; u < NU; ++u) {
             int row, ch;
             if (piece(u, l, row, ch)) {
-                const bool ok = row < 256;
+                bool ok = row < ZROW;
                 unsigned pix;
-                if (KIND == 1) {
+                if (BAND) {
+                    const int f = tile >> 2, y = (tile & 3) * 8 + row / S - 1, x = row % S;      // 4 bands per frame; LDS row 0 = the halo row above
+                    ok = ok && y >= 0 && y < S;
+                    pix = KIND == 1 ? (unsigned)((f * 2 * S + 2 * y + py) * 2 * S + 2 * x + px) : (unsigned)((f * S + y) * S + x);
+                } else if (KIND == 1) {
                     const int fl = row / (S * S), y = (row / S) % S, x = row % S;
                     pix = (unsigned)(((tile * NP + fl) * 2 * S + 2 * y + py) * 2 * S + 2 * x + px);
                 } else pix = (unsigned)tile * 256u + row;
@@ -513,12 +529,12 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
         }
     };
     auto ldA1 = [&](int sl, int tm, int ks) -> uint4 {
-        return *reinterpret_cast<const uint4*>(ring + sl * WS_SLAB + ((aoff + tm * 2048) ^ (ks * 64)));
+        return *reinterpret_cast<const uint4*>(ring + sl * SLAB + ((aoff + tm * 2048) ^ (ks * 64)));
     };
     auto flip_buffers = [&](int to_buf1) {
         const int d = to_buf1 ? HBUF : -HBUF;
 #pragma unroll
-        for (int tn = 0; tn < 4; ++tn)
+        for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) b3[tn][dx] += d;
 #pragma unroll
@@ -532,11 +548,11 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
     __builtin_amdgcn_s_barrier();
 
     int cslot = 0, hbuf = 0;
-    f32x4 acc[4][4];
+    f32x4 acc[4][TN];
     // one K chunk = 4 taps (EY + ky, EX + kx) on input buffer hbuf; (tnext, ccnext) = the buffer to fetch meanwhile (conv3x3_ws_kernel's
     // schedule: the pieces issued at tap 0 are older than the slab tap 2's sync waits for)
     auto run_chunk = [&](auto after_epi, auto ey_, auto ex_, int tnext, int ccnext) {
-        constexpr int EPI = decltype(after_epi)::value ? WS_STORES : 0;
+        constexpr int EPI = decltype(after_epi)::value ? STORES : 0;
         constexpr int EY = decltype(ey_)::value, EX = decltype(ex_)::value;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -550,9 +566,9 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
             issue_w();
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                uint4 b[4];
+                uint4 b[TN];
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
+                for (int tn = 0; tn < TN; ++tn) {
                     int a = b3[tn][dx];
                     a = tap_valid(tn, dy, dx) ? a : zs[dy];
                     b[tn] = *reinterpret_cast<const uint4*>(smem + ((a ^ (ks * 64)) + dy * DYB));
@@ -561,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
                 for (int tm = 0; tm < 4; ++tm) {
                     const uint4 a = ldA1(cslot, tm, ks);
 #pragma unroll
-                    for (int tn = 0; tn < 4; ++tn) M::mma(acc[tm][tn], a, b[tn]);
+                    for (int tn = 0; tn < TN; ++tn) M::mma(acc[tm][tn], a, b[tn]);
                 }
             }
             if (k == 3) flip_buffers(hbuf ^ 1);
@@ -580,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
-            for (int tn = 0; tn < 4; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int cc = 0; cc < nchunks; ++cc) {
             const bool last = (cc + 1 == nchunks);
             const int tnext = last ? (t + 1 < t1 ? t + 1 : t) : t, ccnext = last ? 0 : cc + 1;
@@ -595,12 +611,12 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
             size_t tile_pix;
             if (KIND == 1) tile_pix = (size_t)t * 256;
             else tile_pix = (size_t)(t >> 2) * 1024 + (size_t)(((t & 3) >> 1) * 2 * S + (t & 1));     // 4 output pixels per input pixel; phase offset
-            const int cobase = j * 128 + wc * 64 + 4 * q;
+            const int cobase = j * BCO + wc * 64 + 4 * q;
 #pragma unroll
             for (int tm = 0; tm < 4; ++tm) {
                 const float4 bs = *reinterpret_cast<const float4*>(biasl + wc * 64 + tm * 16 + 4 * q);
 #pragma unroll
-                for (int tn = 0; tn < 4; ++tn) {
+                for (int tn = 0; tn < TN; ++tn) {
                     const float4 v = make_float4(acc[tm][tn][0] + bs.x, acc[tm][tn][1] + bs.y, acc[tm][tn][2] + bs.z, acc[tm][tn][3] + bs.w);
                     const size_t e = (tile_pix + opix[tn]) * P.Cout + cobase + tm * 16;
                     if (P.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.y) + e * 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
@@ -630,6 +646,7 @@ static int ws4_geo(const ConvArgs& a) {
     if (!down && !up) return 0;
     const int s = down ? a.H / 2 : a.H;
     if (a.H != a.W || (down && (a.H % 2))) return 0;
+    if (s == 32) return 32;                               // bands of 8 rows
     if (s == 16) return 16;
     if (s == 8 && a.NF % 4 == 0) return 8;
     return 0;
@@ -639,8 +656,8 @@ bool conv4x4_ws_eligible(int mode, const ConvArgs& a) {
     if (mode != MODE_BF16 || a.res || a.pro || a.out_stats || a.C1 || !a.x0_bf16) return false;
     const int geo = ws4_geo(a);
     if (!geo) return false;
-    if (a.C0 % 64 || a.Cout % 128 || a.CinPad != a.C0) return false;
-    const int nct = a.Cout / 128;
+    if (a.C0 % 64 || (a.Cout % 128 && a.Cout != 64) || a.CinPad != a.C0) return false;
+    const int nct = a.Cout == 64 ? 1 : a.Cout / 128;
     if (nct != 1 && nct != 2 && nct != 4 && nct != 8) return false;
     if (a.wrows != a.Cout || a.wrow0 != 0) return false;
     const long vtiles = (long)a.NF * geo * geo / 256 * (a.kind == 1 ? 4 : 1);
@@ -650,7 +667,7 @@ bool conv4x4_ws_eligible(int mode, const ConvArgs& a) {
 }
 
 hipError_t launch_conv4x4_ws(const ConvArgs& a, hipStream_t st) {
-    const int geo = ws4_geo(a), nct = a.Cout / 128, up = a.kind == 1;
+    const int geo = ws4_geo(a), bco = a.Cout == 64 ? 64 : 128, nct = a.Cout / bco, up = a.kind == 1;
     const int total = (int)((long)a.NF * geo * geo / 256) * (up ? 4 : 1);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
@@ -660,15 +677,19 @@ hipError_t launch_conv4x4_ws(const ConvArgs& a, hipStream_t st) {
     const int nranges = grid / nct;
     int tpr = (total + nranges - 1) / nranges;
     if (up) tpr = (tpr + 3) / 4 * 4;                      // a range = whole groups of 4 phases (the weight stream's phase follows t & 3)
-    const size_t lds = (size_t)WS_NS * WS_SLAB + 2 * (size_t)257 * 128 + 512;
+    const size_t lds = (size_t)WS_NS * bco * 128 + 2 * (size_t)(geo == 32 ? 321 : 257) * 128 + 512;
     auto go = [&](auto kfn) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a, tpr, total, nct);
         return hipGetLastError();
     };
-    if (geo == 8) return up ? go(conv4x4_ws_kernel<8, 2>) : go(conv4x4_ws_kernel<8, 1>);
-    return up ? go(conv4x4_ws_kernel<16, 2>) : go(conv4x4_ws_kernel<16, 1>);
+#define VDX_WS4(G_) do { if (bco == 64) return up ? go(conv4x4_ws_kernel<G_, 2, 64>) : go(conv4x4_ws_kernel<G_, 1, 64>);       \
+                         return up ? go(conv4x4_ws_kernel<G_, 2, 128>) : go(conv4x4_ws_kernel<G_, 1, 128>); } while (0)
+    if (geo == 8) VDX_WS4(8);
+    if (geo == 16) VDX_WS4(16);
+    VDX_WS4(32);
+#undef VDX_WS4
 }
 
 bool conv3x3_ws_eligible(int mode, const ConvArgs& a) {
