@@ -8,9 +8,9 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/traffic_$name
 rm -rf "$out"; mkdir -p "$out/f" "$out/w"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/f" -- python3 "$root/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-roofline "$@" > "$out/f/log.txt" 2>&1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/f" -- python3 "$root/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-train "$@" > "$out/f/log.txt" 2>&1
 echo "fetch pass done" >> "$out/progress.txt"
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/w" -- python3 "$root/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-roofline "$@" > "$out/w/log.txt" 2>&1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/w" -- python3 "$root/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-train "$@" > "$out/w/log.txt" 2>&1
 echo "write pass done" >> "$out/progress.txt"
 python3 - "$out" "$root/gpurun_out/$name.json" "$@" <<'PY'
 import collections, csv, json, pathlib, sys
