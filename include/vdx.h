@@ -106,6 +106,17 @@ int vdx_resblock_tail(const float* y2, const float* r, float* out, const double*
                       const float* gn_beta, int groups, const float* ln_gamma, const float* ln_beta, int c, int batch,
                       long pix_per_sample, void* stream);
 
+/* ResnetBlock tail with the block's 1x1 res_conv inside (reference: modules.py:219-222 `res_conv` + :240-243
+ * `h + norm_2(res_conv(x))`), bf16 tensors (bf16 activation storage of a bf16-mode network):
+ * out = SiLU(GroupNorm(y2)) + LayerNorm_C(concat(x0[..,c0], x1[..,c1]) . W + rc_bias).  y2, x0, x1, out: bf16 channel-last;
+ * rc_w_packed: bf16 [c][c0 + c1] (row = output channel, K-contiguous: the packing vdx_pack_params produces for this conv);
+ * x1 may be NULL with c1 = 0.  Shapes served: (c0 + c1, c) in {(128,64), (64,128), (256,64), (128,256)}, c1 = 0 or c1 = c0,
+ * pix_per_sample a multiple of 16; anything else returns VDX_ERR_INVALID. */
+int vdx_resblock_tail_rc_bf16(const void* y2, const void* x0, const void* x1, int c0, int c1, const void* rc_w_packed,
+                              const float* rc_bias, void* out, const double* stats, const float* gn_gamma, const float* gn_beta,
+                              int groups, const float* ln_gamma, const float* ln_beta, int c, int batch, long pix_per_sample,
+                              void* stream);
+
 /* init_conv (reference: unet3d.py:110-115,282): x EXTERNAL layout [B,Cin,F,H,W], Flax kernel (1,k,k,Cin,Cout) fp32,
  * y channel-last [B,F,H,W,Cout]. */
 int vdx_init_conv(const float* x, const float* kernel, const float* bias, float* y, int batch, int cin, int frames,

@@ -39,6 +39,47 @@ def test_resblock_tail(C, B, shape):
     assert _rel(out.cpu().double(), ref) < 2e-6
 
 
+@pytest.mark.parametrize('c0,c1,C,B,shape', [(64, 64, 64, 2, (4, 16, 16)), (64, 0, 128, 1, (3, 8, 8)), (128, 128, 64, 2, (2, 8, 8)),
+                                             (128, 0, 256, 1, (5, 4, 4)), (256, 0, 64, 1, (4, 32, 32)), (64, 64, 64, 3, (16, 64, 64))])
+def test_resblock_tail_with_res_conv_bf16(c0, c1, C, B, shape):
+    """resblock_tail_rc16_kernel (bf16 activation storage): the block's 1x1 res_conv computed inside the tail from the (concat) block
+    input.  Reference = the oracle ops in fp64 on the SAME bf16-rounded tensors and bf16-rounded res_conv weights; the kernel
+    accumulates in fp32 and rounds only its output to bf16 (2^-9 relative per element)."""
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(c0 + C)
+    bf = torch.bfloat16
+    y2 = (torch.randn(B, *shape, C, generator=g) * 2 + 0.5).to(bf)
+    x0 = torch.randn(B, *shape, c0, generator=g).to(bf)
+    x1 = torch.randn(B, *shape, c1, generator=g).to(bf) if c1 else None
+    w = torch.randn(c0 + c1, C, generator=g) / (c0 + c1) ** 0.5
+    rb = 0.3 * torch.randn(C, generator=g)
+    gg, gb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    lg, lb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    yg = y2.double().reshape(B, -1, 8, C // 8)
+    stats = torch.zeros(B, 32, 8, 2, dtype=torch.float64)
+    stats[:, 3, :, 0] = yg.sum(dim=(1, 3)); stats[:, 3, :, 1] = (yg * yg).sum(dim=(1, 3))
+    out = ops.resblock_tail_rc_bf16(y2.to(DEV), x0.to(DEV), None if x1 is None else x1.to(DEV), w.to(DEV), rb.to(DEV),
+                                    stats.reshape(-1).to(DEV), gg.to(DEV), gb.to(DEV), lg.to(DEV), lb.to(DEV))
+    x = x0.double() if x1 is None else torch.cat([x0.double(), x1.double()], dim=-1)
+    r = x @ w.to(bf).double() + rb.double()
+    ref = R.silu(R.group_norm(y2.double(), gg.double(), gb.double(), 8)) + R.layer_norm(r, lg.double(), lb.double())
+    assert out.dtype == bf
+    assert _rel(out.cpu().double(), ref) < 3e-3                         # bf16 output rounding: 2^-9 / sqrt(3) ~ 1.1e-3 rms
+    assert (out.cpu().double() - ref).abs().max() < 2e-2 * ref.abs().max()
+
+
+def test_resblock_tail_with_res_conv_rejects_unserved_shapes():
+    from video_diffusion_nnx_amd import ops
+    from video_diffusion_nnx_amd._lib import VdxError
+    bf = torch.bfloat16
+    y2 = torch.zeros(1, 2, 4, 4, 96, dtype=bf, device=DEV)
+    x0 = torch.zeros(1, 2, 4, 4, 64, dtype=bf, device=DEV)
+    z = torch.zeros(96, device=DEV)
+    with pytest.raises(VdxError):
+        ops.resblock_tail_rc_bf16(y2, x0, None, torch.zeros(64, 96, device=DEV), z, torch.zeros(32 * 8 * 2, dtype=torch.float64, device=DEV),
+                                  z, z, z, z)
+
+
 @pytest.mark.parametrize('Cin,D,k', [(1, 64, 7), (3, 16, 7), (3, 40, 3)])
 def test_init_conv(Cin, D, k):
     from video_diffusion_nnx_amd import ops

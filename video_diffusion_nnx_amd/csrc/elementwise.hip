@@ -140,7 +140,168 @@ __global__ __launch_bounds__(256) void resblock_tail16_kernel(TailArgs P) {
     }
 }
 
+// ---- tail with the 1x1 res_conv inside (bf16 tensors, bf16 MFMA operands) ---------------------------------------------------------
+// out = SiLU(GroupNorm(y2)) + LayerNorm_C(concat(x0, x1) . W_rc + b_rc)   modules.py:219-222 (res_conv) + :240-243
+// The separate 1x1 conv read the block input (2E at level 0, a concat) and wrote r (E) for the tail to read again; here a wave takes
+// 16 pixels, fetches their x rows straight into MFMA B fragments (lane (pixel, q) = 16 bytes of a 64-byte K chunk) and multiplies
+// with the weight image kept in LDS.  The A-tile rows are PERMUTED so that the accumulators of lane (pixel, q) are the channels
+// {32j + 8q .. 32j + 8q + 7}: whole 16-byte pieces of the bf16 rows of y2 / out, i.e. the tail's own access pattern.  r never
+// exists in HBM and is not rounded to bf16 before the LayerNorm.  Loads of the next 16-pixel group are in flight during the
+// arithmetic of the current one (two register sets, ping-pong).  Addresses are per-sample buffer descriptors + one 32-bit row
+// offset per tensor + immediates.  CAT: the input is a concat of two CIN/2-channel tensors.
+typedef unsigned tu32x4 __attribute__((ext_vector_type(4)));
+
+template <int CIN, int COUT, bool CAT>
+__global__ __launch_bounds__(256, (CIN == 128 && COUT == 64) ? 4 : (COUT <= 128 ? 3 : 2)) void resblock_tail_rc16_kernel(TailArgs P) {
+    using M = Mma<MODE_BF16>;
+    constexpr int NTM = COUT / 16, NKS = CIN / 32, NH = COUT / 32;
+    constexpr int C0 = CAT ? CIN / 2 : CIN, NK0 = C0 / 32;
+    constexpr int WRS = CIN * 2 + 16;                       // LDS row stride of the weight image (bytes)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Wl = smem;                                        // [COUT rows, A-tile order][WRS]
+    float* coefA = reinterpret_cast<float*>(Wl + COUT * WRS);
+    float* coefD = coefA + COUT;
+    float* lng = coefD + COUT;
+    float* lnb = lng + COUT;
+    float* rcb = lnb + COUT;
+    float* gm = rcb + COUT;                                 // [32][mean, rstd]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, q = lane >> 4;
+    const int b = blockIdx.y;
+    for (int i = tid; i < COUT * (CIN / 8); i += 256) {
+        const int row = i / (CIN / 8), c = i % (CIN / 8);
+        const int tm = row >> 4, rr = row & 15;
+        const int co = (tm >> 1) * 32 + (rr >> 2) * 8 + (tm & 1) * 4 + (rr & 3);
+        *reinterpret_cast<uint4*>(Wl + row * WRS + c * 16) =
+            *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.rc_w) + ((size_t)co * CIN + c * 8) * 2);
+    }
+    gn_mean_rstd_wg(P.stats, b, P.groups, (double)P.pix_per_sample * (COUT / P.groups), gm, tid, 256);
+    __syncthreads();
+    for (int c = tid; c < COUT; c += 256) {
+        const int g = c / (COUT / P.groups);
+        const float a = gm[2 * g + 1] * P.gn_gamma[c];
+        coefA[c] = a;
+        coefD[c] = P.gn_beta[c] - gm[2 * g] * a;
+        lng[c] = P.ln_gamma[c]; lnb[c] = P.ln_beta[c]; rcb[c] = P.rc_b[c];
+    }
+    __syncthreads();
+
+    const unsigned pps = (unsigned)P.pix_per_sample;
+    const char* x0p = reinterpret_cast<const char*>(P.x0) + (size_t)b * pps * C0 * 2;
+    const char* x1p = CAT ? reinterpret_cast<const char*>(P.x1) + (size_t)b * pps * C0 * 2 : x0p;
+    const char* y2p = reinterpret_cast<const char*>(P.y2) + (size_t)b * pps * COUT * 2;
+    char* outp = reinterpret_cast<char*>(P.out) + (size_t)b * pps * COUT * 2;
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x0p), 0, pps * C0 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x1p), 0, pps * C0 * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(y2p), 0, pps * COUT * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(outp, 0, pps * COUT * 2, 0x00020000);
+    const int ngroups = (int)(pps >> 4);
+    const int gstride = (int)gridDim.x * 4;
+    const unsigned lane_x = lp * (C0 * 2) + q * 16, lane_y = lp * (COUT * 2) + q * 16;
+
+    auto issue = [&](int g, tu32x4 (&xf)[NKS], tu32x4 (&yf)[NH]) {
+        const unsigned ox = (unsigned)g * (16 * C0 * 2) + lane_x, oy = (unsigned)g * (16 * COUT * 2) + lane_y;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s)
+            xf[s] = (s < NK0) ? __builtin_amdgcn_raw_buffer_load_b128(rx0, ox + s * 64, 0, 0)
+                              : __builtin_amdgcn_raw_buffer_load_b128(rx1, ox + (s - NK0) * 64, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NH; ++j) yf[j] = __builtin_amdgcn_raw_buffer_load_b128(ry, oy + j * 64, 0, 0);
+    };
+    auto compute = [&](int g, const tu32x4 (&xf)[NKS], const tu32x4 (&yf)[NH]) {
+        // the weight fragments and coefficients are re-read from LDS for every group: hoisted out of the loop they take ~150 registers
+        // and leave one wave per SIMD, far too few loads in flight for a streaming kernel
+        __asm__ volatile("" ::: "memory");
+        f32x4 acc[NTM];
+#pragma unroll
+        for (int tm = 0; tm < NTM; ++tm) {
+            const float4 b4 = *reinterpret_cast<const float4*>(rcb + (tm >> 1) * 32 + q * 8 + (tm & 1) * 4);
+            acc[tm] = f32x4{b4.x, b4.y, b4.z, b4.w};
+        }
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const uint4 bx = make_uint4(xf[s].x, xf[s].y, xf[s].z, xf[s].w);
+#pragma unroll
+            for (int tm = 0; tm < NTM; ++tm)
+                M::mma(acc[tm], *reinterpret_cast<const uint4*>(Wl + (tm * 16 + lp) * WRS + s * 64 + q * 16), bx);
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int tm = 0; tm < NTM; ++tm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1 += acc[tm][e]; s2 += acc[tm][e] * acc[tm][e]; }
+        s1 = reduce_q(s1); s2 = reduce_q(s2);
+        const float mean = s1 * (1.0f / COUT);
+        const float var = fmaxf(s2 * (1.0f / COUT) - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + NORM_EPS);
+        const unsigned oy = (unsigned)g * (16 * COUT * 2) + lane_y;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+            float y[8], o[8];
+            unpack8(make_uint4(yf[j].x, yf[j].y, yf[j].z, yf[j].w), y);
+            const int c0 = j * 32 + q * 8;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float4 a4 = *reinterpret_cast<const float4*>(coefA + c0 + 4 * h), d4 = *reinterpret_cast<const float4*>(coefD + c0 + 4 * h);
+                const float4 g4 = *reinterpret_cast<const float4*>(lng + c0 + 4 * h), e4 = *reinterpret_cast<const float4*>(lnb + c0 + 4 * h);
+                const f32x4 r = acc[2 * j + h];
+                o[4 * h + 0] = silu_f(fmaf(y[4 * h + 0], a4.x, d4.x)) + fmaf((r[0] - mean) * rstd, g4.x, e4.x);
+                o[4 * h + 1] = silu_f(fmaf(y[4 * h + 1], a4.y, d4.y)) + fmaf((r[1] - mean) * rstd, g4.y, e4.y);
+                o[4 * h + 2] = silu_f(fmaf(y[4 * h + 2], a4.z, d4.z)) + fmaf((r[2] - mean) * rstd, g4.z, e4.z);
+                o[4 * h + 3] = silu_f(fmaf(y[4 * h + 3], a4.w, d4.w)) + fmaf((r[3] - mean) * rstd, g4.w, e4.w);
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(tu32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])},
+                                                   ro, oy + j * 64, 0, 0);
+        }
+    };
+
+    tu32x4 xa[NKS], ya[NH], xb[NKS], yb[NH];
+    int g = (int)blockIdx.x * 4 + wave;
+    if (g < ngroups) issue(g, xa, ya);
+    while (g < ngroups) {
+        const int g1 = g + gstride;
+        if (g1 < ngroups) issue(g1, xb, yb);
+        compute(g, xa, ya);
+        if (g1 >= ngroups) break;
+        g = g1 + gstride;
+        if (g < ngroups) issue(g, xa, ya);
+        compute(g1, xb, yb);
+    }
+}
+
+bool tail_rc16_supported(int cin, int c0, int cout, long pix_per_sample) {
+    const bool shape = (cin == 128 && cout == 64) || (cin == 64 && cout == 128) || (cin == 256 && cout == 64) || (cin == 128 && cout == 256);
+    return shape && (c0 == cin || 2 * c0 == cin) && pix_per_sample % 16 == 0 && pix_per_sample * std::max(cin, cout) * 2 < (1L << 31);
+}
+
+template <int CIN, int COUT>
+static hipError_t launch_tail_rc16(const TailArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)COUT * (CIN * 2 + 16) + (5 * COUT + 64) * sizeof(float);
+    // every workgroup starts with the weight image + the statistics -> coefficient chain: ~8 passes of 4 x 16 pixels each, but at
+    // least ~2048 workgroups in the launch
+    const long need = (a.pix_per_sample / 16 + 3) / 4;
+    const long gx = std::min<long>(need, std::max<long>(std::max<long>(1, need / 8), (2048 + a.batch - 1) / std::max(1, a.batch)));
+    auto go = [&](auto kfn) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)gx, a.batch), dim3(256), lds, st, a);
+        return hipGetLastError();
+    };
+    return a.C1 ? go(resblock_tail_rc16_kernel<CIN, COUT, true>) : go(resblock_tail_rc16_kernel<CIN, COUT, false>);
+}
+
 hipError_t launch_resblock_tail(TailArgs a, hipStream_t st) {
+    if (a.rc_w) {
+        const int cin = a.C0 + a.C1;
+        if (!(a.y2_bf16 && a.out_bf16) || !a.x0 || (a.C1 && !a.x1) || !a.rc_b || !tail_rc16_supported(cin, a.C0, a.C, a.pix_per_sample))
+            return hipErrorInvalidValue;
+        if (a.groups <= 0 || a.groups > 32 || a.C % a.groups) return hipErrorInvalidValue;
+        if (cin == 128 && a.C == 64) return launch_tail_rc16<128, 64>(a, st);
+        if (cin == 64 && a.C == 128) return launch_tail_rc16<64, 128>(a, st);
+        if (cin == 256 && a.C == 64) return launch_tail_rc16<256, 64>(a, st);
+        return launch_tail_rc16<128, 256>(a, st);
+    }
     if (a.y2_bf16 && a.r_bf16 && a.out_bf16 && a.C % 8 == 0) {
         const int octs = a.C / 8;
         int lpp = 1;

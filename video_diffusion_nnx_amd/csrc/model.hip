@@ -374,7 +374,10 @@ static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, 
     e = launch_conv(m->mode, b, f.st);
     if (e != hipSuccess) return e;
     const float* rsrc = x0;
-    if (r.has_res) {
+    // bf16 activation storage: the 1x1 res_conv runs inside the tail (resblock_tail_rc16_kernel) for the shapes it is built for
+    const bool fuse_rc = r.has_res && f.a16 && m->mode == MODE_BF16 &&
+                         tail_rc16_supported(c0 + c1, c0, r.cout, (long)m->cfg.num_frames * S * S);
+    if (r.has_res && !fuse_rc) {
         ConvArgs c;
         memset(&c, 0, sizeof(c));
         c.x0 = x0; c.x1 = x1; c.C0 = c0; c.C1 = c1;
@@ -391,6 +394,7 @@ static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, 
     t.stats = f.stat(r.st2); t.gn_gamma = f.p + r.b2_gs; t.gn_beta = f.p + r.b2_gb; t.groups = G;
     t.ln_gamma = f.p + r.n2_s; t.ln_beta = f.p + r.n2_b;
     t.C = r.cout; t.batch = f.B; t.pix_per_sample = (long)m->cfg.num_frames * S * S;
+    if (fuse_rc) { t.x0 = x0; t.x1 = x1; t.C0 = c0; t.C1 = c1; t.rc_w = f.pk + r.pk_rc; t.rc_b = f.p + r.rc_b; }
     return launch_resblock_tail(t, f.st);
 }
 

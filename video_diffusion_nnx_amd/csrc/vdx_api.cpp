@@ -129,6 +129,24 @@ int vdx_resblock_tail(const float* y2, const float* r, float* out, const double*
     return VDX_OK;
 }
 
+int vdx_resblock_tail_rc_bf16(const void* y2, const void* x0, const void* x1, int c0, int c1, const void* rc_w_packed,
+                              const float* rc_bias, void* out, const double* stats, const float* gn_gamma, const float* gn_beta,
+                              int groups, const float* ln_gamma, const float* ln_beta, int c, int batch, long pix_per_sample,
+                              void* stream) {
+    if (!y2 || !x0 || !rc_w_packed || !rc_bias || !out || !stats || !gn_gamma || !gn_beta || !ln_gamma || !ln_beta || (c1 && !x1))
+        VDX_FAIL(VDX_ERR_INVALID, "tail_rc: null tensor");
+    if (c1 < 0 || batch < 1 || groups <= 0 || groups > 32 || c % groups || !vdx::tail_rc16_supported(c0 + c1, c0, c, pix_per_sample))
+        VDX_FAIL(VDX_ERR_INVALID, "tail_rc: shape not served");
+    vdx::TailArgs a;
+    memset(&a, 0, sizeof(a));
+    a.y2 = (const float*)y2; a.y2_bf16 = 1; a.out = (float*)out; a.out_bf16 = 1; a.r_bf16 = 1;
+    a.stats = stats; a.gn_gamma = gn_gamma; a.gn_beta = gn_beta; a.groups = groups;
+    a.ln_gamma = ln_gamma; a.ln_beta = ln_beta; a.C = c; a.batch = batch; a.pix_per_sample = pix_per_sample;
+    a.x0 = (const float*)x0; a.x1 = (const float*)x1; a.C0 = c0; a.C1 = c1; a.rc_w = rc_w_packed; a.rc_b = rc_bias;
+    VDX_HIP(vdx::launch_resblock_tail(a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
 int vdx_init_conv(const float* x, const float* kernel, const float* bias, float* y, int batch, int cin, int frames,
                   int h, int w, int cout, int k, void* stream) {
     if (!x || !kernel || !bias || !y) VDX_FAIL(VDX_ERR_INVALID, "init_conv: null tensor");

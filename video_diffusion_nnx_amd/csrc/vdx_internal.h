@@ -47,7 +47,14 @@ struct TailArgs {
     const float* ln_gamma; const float* ln_beta;
     int C; int batch; long pix_per_sample;
     int lpp;                        // completed by the launcher
+    // fused 1x1 res_conv (bf16 tensors, bf16 mode): r = concat(x0[.., C0], x1[.., C1]) . rc_w + rc_b is computed on the MFMA inside
+    // the tail instead of being read from `r` (resblock_tail_rc16_kernel; `r` is ignored when rc_w is set)
+    const float* x0; const float* x1; int C0, C1;
+    const void* rc_w;               // packed [C rows][C0 + C1] bf16 (conv_packed_bytes(MODE_BF16, 1, C0 + C1, C)), or null
+    const float* rc_b;              // [C]
 };
+// shapes resblock_tail_rc16_kernel is instantiated for
+bool tail_rc16_supported(int cin, int c0, int cout, long pix_per_sample);
 
 struct TimeMlpArgs {
     const int* time; int t_is_device_scalar;     // time[b] (or time[0] for every sample)

@@ -71,6 +71,20 @@ def resblock_tail(y2, r, stats, gn_gamma, gn_beta, ln_gamma, ln_beta, groups=8):
     return out
 
 
+def resblock_tail_rc_bf16(y2, x0, x1, rc_kernel, rc_bias, stats, gn_gamma, gn_beta, ln_gamma, ln_beta, groups=8):
+    """Tail with the 1x1 res_conv inside (bf16 tensors): y2 [B,...,C], x0 [B,...,C0], x1 [B,...,C1] or None (all torch.bfloat16),
+    rc_kernel Flax [C0+C1, C] fp32 -> out bf16."""
+    B, C = y2.shape[0], y2.shape[-1]
+    pix = y2.numel() // (B * C)
+    c0, c1 = x0.shape[-1], (0 if x1 is None else x1.shape[-1])
+    wp = rc_kernel.t().contiguous().to(torch.bfloat16)           # [C][Cin], K-contiguous: the packed operand layout
+    out = torch.empty_like(y2)
+    L.check(L.vdx_resblock_tail_rc_bf16(L.ptr(y2), L.ptr(x0), None if x1 is None else L.ptr(x1), c0, c1, L.ptr(wp), L.ptr(rc_bias),
+                                        L.ptr(out), L.ptr(stats), L.ptr(gn_gamma), L.ptr(gn_beta), groups, L.ptr(ln_gamma),
+                                        L.ptr(ln_beta), C, B, pix, L.stream_ptr()))
+    return out
+
+
 def init_conv(x, kernel, bias):
     """x [B,C,F,H,W] (external layout); kernel Flax (1,k,k,C,D) -> [B,F,H,W,D]."""
     B, Cin, Fr, H, W = x.shape
