@@ -649,22 +649,33 @@ static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
 
 // ---- persistent 3x3 conv with Cin = 128 (two-pointer concat of 64 + 64, or one 128-channel tensor), Cout = 64, bf16 inputs ----
 // Same scheme as conv64p_kernel, but a workgroup owns HALF of the output channels (32 x 128 x 9 bf16 weights = 72 KB resident);
-// two workgroups on the same XCD walk the same tile range, so the second reader of a tile finds it in L2.  The 128-channel halo tile
-// (two 64-channel planes, 81 KB) is single-buffered: the next tile is fetched into registers during the MFMAs and written
-// after them.  No prologue (these are the first convs of ResnetBlocks whose input is a concat).
+// two workgroups on the same XCD walk the same tile range, so the second reader of a tile finds it in L2.
+// The 128-channel halo tile does not fit twice beside the weights, so the pipeline runs in PLANE steps (round 2, second form): the
+// two 64-channel planes of the input have one LDS buffer each; while the 72 MFMAs of plane 0 of tile t run, plane 1 of tile t
+// lands in the other buffer by LDS-DMA (global_load_lds, no staging registers, no LDS store instructions), and while plane 1 runs,
+// plane 0 of tile t + 1 lands in the first.  One s_waitcnt vmcnt(0) + barrier per plane step.  (First form: both planes single-
+// buffered, next tile prefetched into 44 registers and written between two barriers with the matrix pipe idle: 758 us per launch at
+// B = 64; this form 626 us.  The MFMA phase itself is LDS-read bound -- one ds_read_b128 per MFMA with 32 x 32 wave tiles.  Measured
+// without gain on top of it: fragment reads software-pipelined two groups ahead of their MFMAs (626 us: LDS latency is not what is
+// exposed); the LDS-DMA pieces issued one per MFMA group instead of all after the barrier (667 us).)
+// A wave-instruction of the DMA covers 8 halo rows x 128 B; lane l fetches the global chunk (l & 7) ^ (l >> 3) of row l >> 3 so that
+// it lands at the swizzled position.  Out-of-image pieces read a zero page.  No prologue (these are the first convs of
+// ResnetBlocks whose input is a concat).
 constexpr int C128_WPL = 9 * 32 * 128;                // bytes per weight plane [9 taps x 32 rows][128 B]
-constexpr int C128_APL = C64_HALO * 128;              // bytes per activation plane
+constexpr int C128_AROWS = 328;                       // 324 halo rows padded to 41 DMA instructions of 8 rows
+constexpr int C128_APL = C128_AROWS * 128;            // bytes per activation plane buffer
+__device__ __attribute__((aligned(16))) unsigned g_zero_page_c128[4];
 
 __global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
     using M = Mma<MODE_BF16>;
-    constexpr int NPIECE = C64_HALO * 16;              // 16-byte pieces of 8 bf16 channels
-    constexpr int NU = (NPIECE + 511) / 512;
+    constexpr int NDMA = 41, NK = (NDMA + 7) / 8;      // DMA instructions per plane; per wave at most NK
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Wl = smem;                                   // [2 planes][288 rows][128 B]
-    char* Al = Wl + 2 * C128_WPL;                      // [2 planes][324 rows][128 B]
+    char* Al = Wl + 2 * C128_WPL;                      // [2 planes][328 rows][128 B]
     float* chs = reinterpret_cast<float*>(Al + 2 * C128_APL);   // [2][32]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int lp = lane & 15, q = lane >> 4;
     // workgroup ids are dealt round-robin to the 8 XCDs: ids i and i + 8 (same XCD, same L2, dispatched together) are the two
     // channel halves of one tile range, so the second reader of a tile finds it in L2 (ids 2r / 2r + 1 sit on different XCDs
@@ -675,8 +686,6 @@ __global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, cons
     const int t0 = range * tiles_per_block, t1 = min(t0 + tiles_per_block, total_tiles);
     if (t0 >= t1) return;
 
-    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x0), 0, P.x0_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x1 ? P.x1 : P.x0), 0, P.x1 ? P.x1_bytes : P.x0_bytes, 0x00020000);
     for (int i = tid; i < 9 * 32 * 16; i += 512) {     // packed [tap][64 co][128 ci] bf16: 256-byte rows
         const int row = i >> 4, c = i & 15;            // row = tap * 32 + local co
         const int tap = row >> 5, col = row & 31;
@@ -685,33 +694,32 @@ __global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, cons
     }
     if (tid < 64) chs[tid] = 0.f;
 
-    int piy[NU], pix_[NU], ploff[NU], pch[NU];
+    // DMA pieces of this lane: instruction u = wave + 8 k covers halo rows 8 u .. 8 u + 7; the lane's row is 8 u + (lane >> 3)
+    int pyx[NK];                                       // (halo row << 5) | halo column; row 100 = padding row / no instruction
+    const int cbyte = ((lane & 7) ^ (lane >> 3)) * 16; // global chunk that lands at LDS position lane & 7 of a row with key lane >> 3
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int i = tid + 512 * u;
-        const int hp = min(i >> 4, C64_HALO - 1), pc = i & 15;
-        piy[u] = (i < NPIECE) ? hp / 18 : -100;
-        pix_[u] = hp % 18;
-        pch[u] = pc * 8;                               // channel of the concat
-        ploff[u] = (pc >> 3) * C128_APL + swz(hp, pc & 7);
+    for (int k = 0; k < NK; ++k) {
+        const int u = wave + 8 * k, hp = u * 8 + (lane >> 3);
+        pyx[k] = (((u < NDMA && hp < C64_HALO) ? hp / 18 : 100) << 5) | (hp % 18);
     }
+    const char* const zero_page = reinterpret_cast<const char*>(g_zero_page_c128);
+    const char* const xb0 = reinterpret_cast<const char*>(P.x0);
+    const char* const xb1 = P.C1 ? reinterpret_cast<const char*>(P.x1) : xb0 + 128;       // plane 1: second tensor, or channels 64..127
+    const int rowb = P.C1 ? 128 : 256;                 // bytes per pixel row of a plane's tensor
+    const unsigned al_base = lds_addr(Al);
     auto decode = [&](int t, int& f, int& ty, int& tx) { f = t / tiles_pf; const int r = t - f * tiles_pf; ty = r / tiles_x; tx = r - ty * tiles_x; };
-    u32x4 sreg[NU];
-    auto stage_load = [&](int t) {
+    auto dma = [&](int t, int pl) {                    // plane pl of tile t -> buffer pl
         int f, ty, tx; decode(t, f, ty, tx);
+        const char* xb = pl ? xb1 : xb0;
+        const unsigned dst = al_base + pl * C128_APL + wave_u * 1024;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int gy = ty * 16 - 1 + piy[u], gx = tx * 16 - 1 + pix_[u];
+        for (int k = 0; k < NK; ++k) {
+            if (wave_u + 8 * k >= NDMA) continue;      // (uniform)
+            const int gy = ty * 16 - 1 + (pyx[k] >> 5), gx = tx * 16 - 1 + (pyx[k] & 31);
             const bool ok = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
-            const int pixel = (f * P.H + gy) * P.W + gx;
-            const bool second = P.C1 && pch[u] >= P.C0;
-            const unsigned off = !ok ? OOB : (second ? (unsigned)(pixel * P.C1 + pch[u] - P.C0) * 2u : (unsigned)(pixel * P.C0 + pch[u]) * 2u);
-            sreg[u] = second ? __builtin_amdgcn_raw_buffer_load_b128(rs1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
+            const size_t off = (size_t)((f * P.H + gy) * P.W + gx) * rowb + cbyte;
+            glds16(ok ? static_cast<const void*>(xb + off) : static_cast<const void*>(zero_page), dst + k * 8 * 1024);
         }
-    };
-    auto stage_store = [&]() {
-#pragma unroll
-        for (int u = 0; u < NU; ++u) if (piy[u] >= 0) *reinterpret_cast<u32x4*>(Al + ploff[u]) = sreg[u];
     };
     f32x4 ssum[2], ssq[2];
 #pragma unroll
@@ -744,19 +752,10 @@ __global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, cons
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) bias4[tm] = P.bias ? *reinterpret_cast<const float4*>(P.bias + co0 + tm * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 
-    int fcur, tyc, txc;
-    decode(t0, fcur, tyc, txc);
-    int bcur = fcur / P.F;
-    stage_load(t0);
-    stage_store();
-    __syncthreads();
-    for (int t = t0; t < t1; ++t) {
-        const bool more = t + 1 < t1;
-        int fn = fcur, tyn = tyc, txn = txc, bn = bcur;
-        if (more) { stage_load(t + 1); decode(t + 1, fn, tyn, txn); bn = fn / P.F; }
-        f32x4 acc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    f32x4 acc[2][2];
+    auto plane_mma = [&](int pl) {                     // 9 taps x 2 chunks x (2 x 2) MFMAs on plane pl
+        const char* Wp = Wl + pl * C128_WPL;
+        const char* Ap = Al + pl * C128_APL;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
@@ -765,20 +764,39 @@ __global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, cons
             for (int tn = 0; tn < 2; ++tn) { const int hp = hpb[tn] + dy * 18 + dx; boff[tn] = swz(hp, q); }
             const int woff = swz(tap * 32 + lp, q);
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl)
+            for (int ch = 0; ch < 2; ++ch) {
+                uint4 af[2], bf[2];
 #pragma unroll
-                for (int ch = 0; ch < 2; ++ch) {
-                    uint4 af[2], bf[2];
+                for (int tm = 0; tm < 2; ++tm) af[tm] = *reinterpret_cast<const uint4*>(Wp + ((woff + tm * 16 * 128) ^ (ch * 64)));
 #pragma unroll
-                    for (int tm = 0; tm < 2; ++tm) af[tm] = *reinterpret_cast<const uint4*>(Wl + pl * C128_WPL + ((woff + tm * 16 * 128) ^ (ch * 64)));
+                for (int tn = 0; tn < 2; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(Ap + (boff[tn] ^ (ch * 64)));
 #pragma unroll
-                    for (int tn = 0; tn < 2; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(Al + pl * C128_APL + (boff[tn] ^ (ch * 64)));
+                for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                        for (int tn = 0; tn < 2; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
-                }
+                    for (int tn = 0; tn < 2; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
+            }
         }
+    };
+
+    int fcur, tyc, txc;
+    decode(t0, fcur, tyc, txc);
+    int bcur = fcur / P.F;
+    dma(t0, 0);
+    wait_vm<0>();
+    __syncthreads();                                   // weights, chs and plane 0 of the first tile visible
+    for (int t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        int fn = fcur, tyn = tyc, txn = txc, bn = bcur;
+        if (more) { decode(t + 1, fn, tyn, txn); bn = fn / P.F; }
+        dma(t, 1);                                     // buffer 1 was last read during plane 1 of tile t - 1 (barrier since)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        plane_mma(0);
+        wait_vm<0>();                                  // this wave's pieces of plane 1 (and the stores of tile t - 1) are done
+        __syncthreads();                               // everybody's are; every wave is done reading buffer 0
+        if (more) dma(t + 1, 0);
+        plane_mma(1);
+        wait_vm<0>();                                  // before the stores below: the wait covers the DMA only
         {
             const int oy0 = tyc * 16 + 2 * wave, ox = txc * 16 + lp;
 #pragma unroll
@@ -794,10 +812,8 @@ __global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, cons
             }
         }
         if (more && bn != bcur) { flush_stats(bcur); bcur = bn; }
-        __syncthreads();                               // every wave is done reading the tile
-        if (more) stage_store();
         fcur = fn; tyc = tyn; txc = txn;
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();                  // plane 0 of tile t + 1 landed everywhere; every wave is done reading buffer 1
     }
     flush_stats(bcur);
 }
