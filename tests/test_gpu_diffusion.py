@@ -126,9 +126,10 @@ def test_p_sample_loop_matches_oracle_loop():
     out_eager = gd.p_sample_loop(shape, seed, use_graph=False)
     torch.cuda.synchronize()
     assert out_graph.shape == shape                                      # gaussian_diffusion_test.py:224-230
-    # GroupNorm partial sums are accumulated with atomics (fp32 in LDS per workgroup, f64 across workgroups): order-dependent
-    # in the last bit, and the 6-step chain amplifies that -- so not bitwise; same tolerance as the oracle check below
-    np.testing.assert_allclose(out_graph.cpu(), out_eager.cpu(), atol=2e-4)
+    # same kernels, same launch order; the GroupNorm partial sums meet in f64 (order-independent), so the replayed graph and the
+    # eager loop agree BITWISE, and so do two runs with the same seed (round 1: fp32 LDS atomics, atol 2e-4)
+    assert torch.equal(out_graph, out_eager)
+    assert torch.equal(out_graph, gd.p_sample_loop(shape, seed, use_graph=True))
     n = int(np.prod(shape))
     ref = DiffusionRef(lambda x, t: R.unet_forward(p, cfg, x, t), image_size=8, num_frames=2, channels=1, timesteps=T, dtype=torch.float64)
     xT = torch.from_numpy(philox_ref.randn(n, seed, 0)).double().reshape(shape)

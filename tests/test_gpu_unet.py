@@ -185,3 +185,19 @@ def test_north_star_shape_bf16_storage_batch8():
     m.load_state_dict(p)
     m.act_bf16 = True
     assert _rel(m(x, t).cpu().double(), ref) < TOL_ACT16
+
+
+@pytest.mark.parametrize('kw,shape', [(dict(dim=16, channels=3), (2, 3, 4, 16, 16)), (dict(dim=64, channels=1), (2, 1, 16, 64, 64))])
+def test_bf16_forward_is_bit_reproducible(kw, shape):
+    """GroupNorm partial sums (fp32 per wave / tile) meet in f64 -- LDS and global atomics whose result does not depend on arrival
+    order, since a few thousand floats add exactly in double -- so two runs of the same bf16-mode forward give identical bits, in both
+    storage formats (round 1: fp32 LDS atomics, ~3e-3 run-to-run jitter at the output)."""
+    cfg, p, m = _build(kw, 'bf16')
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g)
+    t = torch.randint(0, 1000, (shape[0],), generator=g)
+    for act16 in (False, True):
+        m.act_bf16 = act16
+        runs = [m(x, t).clone() for _ in range(3)]
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), f'act_bf16={act16}'
+    m.act_bf16 = False

@@ -75,7 +75,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
 
     // ---- LDS carve (every offset a multiple of 16 bytes) ------------------------------------------
     size_t off = 0;
-    float* chs = reinterpret_cast<float*>(smem + off); off += 2 * BC * 4;          // [2][BC] channel sum / sumsq
+    // fp32 partial sums meet in f64: adding a few dozen floats in double is exact, so neither these LDS atomics nor the f64 global
+    // atomics of the slab depend on the order the waves arrive in (bf16 sampling is bit-reproducible run to run)
+    double* chs = reinterpret_cast<double*>(smem + off); off += 2 * BC * 8;        // [2][BC] channel sum / sumsq
     int* hp_pix = reinterpret_cast<int*>(smem + off); off += ((HPX * 4 + 15) / 16) * 16;   // [HPX] global pixel or -1
     float* coefA = nullptr; float* coefD = nullptr; float* gmean = nullptr;
     if (P.pro) {
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
     char* As = smem + off; off += (size_t)HPX * RS;
     char* Ws = smem + off;                                                          // [NSW][BC rows][128 B] (swizzled, filled by LDS-DMA)
 
-    for (int i = tid; i < 2 * BC; i += NT) chs[i] = 0.f;
+    for (int i = tid; i < 2 * BC; i += NT) chs[i] = 0.0;
     for (int hp = tid; hp < HPX; hp += NT) {
         const int patch = div_magic(hp, P.m_ihiw);
         const int r = hp - patch * (IH * IW);
@@ -353,17 +355,17 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
             const float s4 = reduce16((s.x + s.y) + (s.z + s.w)), q4 = reduce16((ss.x + ss.y) + (ss.z + ss.w));
             if (lp == 0 && cvalid) {
                 const int gl = co / st_cpg - st_glo;
-                atomicAdd(&chs[gl], s4); atomicAdd(&chs[BC + gl], q4);
+                unsafeAtomicAdd(&chs[gl], (double)s4); unsafeAtomicAdd(&chs[BC + gl], (double)q4);
             }
         } else if (P.out_stats) {
             s.x = reduce16(s.x); s.y = reduce16(s.y); s.z = reduce16(s.z); s.w = reduce16(s.w);
             ss.x = reduce16(ss.x); ss.y = reduce16(ss.y); ss.z = reduce16(ss.z); ss.w = reduce16(ss.w);
             if (lp == 0) {
                 const int lc = wc * 64 + tm * 16 + q * 4;
-                atomicAdd(&chs[lc + 0], s.x); atomicAdd(&chs[lc + 1], s.y);
-                atomicAdd(&chs[lc + 2], s.z); atomicAdd(&chs[lc + 3], s.w);
-                atomicAdd(&chs[BC + lc + 0], ss.x); atomicAdd(&chs[BC + lc + 1], ss.y);
-                atomicAdd(&chs[BC + lc + 2], ss.z); atomicAdd(&chs[BC + lc + 3], ss.w);
+                unsafeAtomicAdd(&chs[lc + 0], (double)s.x); unsafeAtomicAdd(&chs[lc + 1], (double)s.y);
+                unsafeAtomicAdd(&chs[lc + 2], (double)s.z); unsafeAtomicAdd(&chs[lc + 3], (double)s.w);
+                unsafeAtomicAdd(&chs[BC + lc + 0], (double)ss.x); unsafeAtomicAdd(&chs[BC + lc + 1], (double)ss.y);
+                unsafeAtomicAdd(&chs[BC + lc + 2], (double)ss.z); unsafeAtomicAdd(&chs[BC + lc + 3], (double)ss.w);
             }
         }
     }
@@ -377,11 +379,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
         if (tid < 2 * ng) {
             const int g = g_lo + (tid >> 1), which = tid & 1;
             const int lo = max(g * cpg, c0), hi = min((g + 1) * cpg, c_hi);
-            float t = 0.f;
+            double t = 0.0;
             if (grp4) t = chs[which * BC + (tid >> 1)];
             else for (int c = lo; c < hi; ++c) t += chs[which * BC + (c - c0)];
             const int slot = (blockIdx.x + blockIdx.z * 7) % GN_SLOTS;
-            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + slot) * P.out_groups + g) * 2 + which, (double)t);
+            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + slot) * P.out_groups + g) * 2 + which, t);
         }
     }
 }
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     float* coefA = reinterpret_cast<float*>(Al + 2 * C64_HALO * 128);
     float* coefD = coefA + 64;
     float* gmean = coefD + 64;                        // [32][mean, rstd]
-    float* chs = gmean + 64;                          // [2][64] channel sum / sumsq of the current sample
+    double* chs = reinterpret_cast<double*>(gmean + 64);   // [2][64] channel sum / sumsq of the current sample (f64: order-independent)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
         const int row = i >> 3, c = i & 7;
         *reinterpret_cast<uint4*>(Wl + swz(row, c)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) + (size_t)row * 128 + c * 16);
     }
-    if (tid < 128) chs[tid] = 0.f;
+    if (tid < 128) chs[tid] = 0.0;
 
     // per-thread staging pieces (constant over tiles): halo position, channel piece, LDS byte offset
     // (register budget: 256 at 2 waves per SIMD and the prologue forms sit on it -- the halo row / column share one register, the
@@ -520,19 +522,19 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float s1 = reduce16(ssum[tm][e]), s2 = reduce16(ssq[tm][e]);
-                if (lp == 0) { atomicAdd(&chs[tm * 16 + 4 * q + e], s1); atomicAdd(&chs[64 + tm * 16 + 4 * q + e], s2); }
+                if (lp == 0) { unsafeAtomicAdd(&chs[tm * 16 + 4 * q + e], (double)s1); unsafeAtomicAdd(&chs[64 + tm * 16 + 4 * q + e], (double)s2); }
                 ssum[tm][e] = 0.f; ssq[tm][e] = 0.f;
             }
         __syncthreads();
         const int cpg = 64 / P.out_groups;
         if (tid < 2 * P.out_groups) {
             const int g = tid >> 1, which = tid & 1;
-            float t = 0.f;
+            double t = 0.0;
             for (int c = g * cpg; c < (g + 1) * cpg; ++c) t += chs[which * 64 + c];
-            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * P.out_groups + g) * 2 + which, (double)t);
+            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * P.out_groups + g) * 2 + which, t);
         }
         __syncthreads();
-        if (tid < 128) chs[tid] = 0.f;
+        if (tid < 128) chs[tid] = 0.0;
         __syncthreads();
     };
 
@@ -627,7 +629,7 @@ static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
     const int grid = std::min(total, cus);
     const int tpb = (total + grid - 1) / grid;
     const int nblocks = (total + tpb - 1) / tpb;
-    const size_t lds = 9 * 64 * 128 + 2 * (size_t)C64_HALO * 128 + (64 + 64 + 64 + 128) * 4;
+    const size_t lds = 9 * 64 * 128 + 2 * (size_t)C64_HALO * 128 + (64 + 64 + 64) * 4 + 128 * 8;
     auto launch = [&](auto kfn) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, cons
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Wl = smem;                                   // [2 planes][288 rows][128 B]
     char* Al = Wl + 2 * C128_WPL;                      // [2 planes][328 rows][128 B]
-    float* chs = reinterpret_cast<float*>(Al + 2 * C128_APL);   // [2][32]
+    double* chs = reinterpret_cast<double*>(Al + 2 * C128_APL); // [2][32] (f64: order-independent)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, cons
         const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) + ((size_t)(tap * 64 + co0 + col) * 256) + c * 16);
         *reinterpret_cast<uint4*>(Wl + (c >> 3) * C128_WPL + swz(row, c & 7)) = v;
     }
-    if (tid < 64) chs[tid] = 0.f;
+    if (tid < 64) chs[tid] = 0.0;
 
     // DMA pieces of this lane: instruction u = wave + 8 k covers halo rows 8 u .. 8 u + 7; the lane's row is 8 u + (lane >> 3)
     int pyx[NK];                                       // (halo row << 5) | halo column; row 100 = padding row / no instruction
@@ -731,19 +733,19 @@ __global__ __launch_bounds__(512) void conv128x64p_kernel(const ConvArgs P, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float s1 = reduce16(ssum[tm][e]), s2 = reduce16(ssq[tm][e]);
-                if (lp == 0) { atomicAdd(&chs[tm * 16 + 4 * q + e], s1); atomicAdd(&chs[32 + tm * 16 + 4 * q + e], s2); }
+                if (lp == 0) { unsafeAtomicAdd(&chs[tm * 16 + 4 * q + e], (double)s1); unsafeAtomicAdd(&chs[32 + tm * 16 + 4 * q + e], (double)s2); }
                 ssum[tm][e] = 0.f; ssq[tm][e] = 0.f;
             }
         __syncthreads();
         const int cpg = 64 / P.out_groups, ng = 32 / cpg;       // groups inside this half
         if (tid < 2 * ng) {
             const int g = tid >> 1, which = tid & 1;
-            float t = 0.f;
+            double t = 0.0;
             for (int c = g * cpg; c < (g + 1) * cpg; ++c) t += chs[which * 32 + c];
-            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + ((blockIdx.x >> 1) % GN_SLOTS)) * P.out_groups + half * ng + g) * 2 + which, (double)t);
+            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + ((blockIdx.x >> 1) % GN_SLOTS)) * P.out_groups + half * ng + g) * 2 + which, t);
         }
         __syncthreads();
-        if (tid < 64) chs[tid] = 0.f;
+        if (tid < 64) chs[tid] = 0.0;
         __syncthreads();
     };
     int hpb[2];
@@ -825,7 +827,7 @@ static hipError_t launch_conv128x64p(const ConvArgs& a, hipStream_t st) {
     const int ranges = std::max(1, std::min(total, cus / 2));
     const int tpb = (total + ranges - 1) / ranges;
     const int nranges = (total + tpb - 1) / tpb;
-    const size_t lds = 2 * (size_t)C128_WPL + 2 * (size_t)C128_APL + 64 * 4;
+    const size_t lds = 2 * (size_t)C128_WPL + 2 * (size_t)C128_APL + 64 * 8;
     auto kfn = conv128x64p_kernel;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1048,7 +1050,7 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     auto magic = [](int d) { return (unsigned)((1ull << 32) / (unsigned)d) + 1u; };      // every divisor here is >= 2
     a.m_ihiw = magic(IH * IW); a.m_iw = magic(IW); a.m_phpw = magic(a.PH * a.PW); a.m_pw = magic(a.PW);
     if (IW < 2 || a.PW < 2) return hipErrorInvalidValue;
-    size_t lds = 2 * BC * 4 + ((HPX * 4 + 15) / 16) * 16 + (a.pro ? (2 * a.CinPad * 4 + 64 * 4) : 0)
+    size_t lds = 2 * BC * 8 + ((HPX * 4 + 15) / 16) * 16 + (a.pro ? (2 * a.CinPad * 4 + 64 * 4) : 0)
                + (size_t)HPX * ROW_STRIDE + 3 * (size_t)BC * 128;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     dim3 grid((a.NF / a.NP) * a.tiles_y * a.tiles_x, (a.Cout + BC - 1) / BC, a.kind ? 4 : 1);
