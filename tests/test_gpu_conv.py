@@ -232,6 +232,47 @@ def test_weight_streaming_conv(case, y_bf16):
         assert r2 < 5e-3, (use_ss, r2)
 
 
+PW_CASES = [
+    # B, F, S, C0, C1, Cout, res      (1x1, bf16 tensors, Cin % 128 == 0, Cout % 64 == 0 and >= 128, >= 8192 pixels)
+    (8, 16, 8, 256, 0, 512, False),    # downs.3.0 res_conv: 128-row tiles, 2 K blocks
+    (8, 16, 8, 512, 512, 256, False),  # ups.0.0 res_conv on a concat: 64-row tiles (Cin = 1024), two-pointer K blocks
+    (2, 16, 16, 256, 256, 128, False), # ups.1.0 res_conv: Cin = 512, one 128-row tile
+    (2, 16, 16, 256, 0, 256, True),    # level-2 attention / SLA to_out: + residual
+    (9, 16, 8, 256, 0, 512, True),     # level-3 to_out, 9216 pixels: ragged pixel ranges
+    (4, 8, 16, 128, 0, 192, True),     # one K block, three 64-row tiles
+]
+
+
+@pytest.mark.parametrize('case', PW_CASES)
+def test_pointwise_conv_bf16(case):
+    """conv1x1_pw_kernel (conv_pw.hip): the 1x1 convs of the wide levels on bf16 tensors -- weight rows resident in LDS, x rows straight
+    from global memory into MFMA fragments, permuted output rows, optional residual.  Reference: fp64 matmul of the bf16-rounded
+    operands; one output rounding to bf16."""
+    from video_diffusion_nnx_amd import ops
+    dev = torch.device('cuda:0')
+    B, Fr, S, C0, C1, Cout, with_res = case
+    g = torch.Generator().manual_seed(sum(case[:6]))
+    bf = torch.bfloat16
+    x = torch.randn(B, Fr, S, S, C0 + C1, generator=g).to(bf)
+    kern = torch.randn(1, C0 + C1, Cout, generator=g) / (C0 + C1) ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Fr, S, S, Cout, generator=g).to(bf) if with_res else None
+    pw = ops.pack_conv_weights(kern.to(dev), 'bf16')
+    xd = x.to(dev)
+    kw = dict(mode='bf16', bias=bias.to(dev), k=1, y_bf16=True, res=None if res is None else res.to(dev))
+    if C1:
+        y = ops.conv_forward(xd[..., :C0].contiguous(), pw, Cout, x1=xd[..., C0:].contiguous(), **kw)
+    else:
+        y = ops.conv_forward(xd, pw, Cout, **kw)
+    torch.cuda.synchronize()
+    ref = x.double() @ _bf16r(kern[0]).double() + bias.double()
+    if with_res:
+        ref = ref + res.double()
+    assert y.dtype == bf
+    assert _rel(y.float().cpu().double(), ref) < 4e-3
+    assert (y.float().cpu().double() - ref).abs().max() < 2e-2 * ref.abs().max()
+
+
 WS4_CASES = [
     # kind (0 = Downsample 4x4 / stride 2, 1 = Upsample ConvTranspose), B, F, S_in, C, Cout   (bf16 tensors; >= 128 work items)
     (0, 8, 16, 32, 128, 128),          # level-1 Downsample: 32 -> 16, whole 16 x 16 output frames, 2 K chunks per parity plane

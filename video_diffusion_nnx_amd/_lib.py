@@ -43,6 +43,7 @@ class ConvDesc(C.Structure):
         ('scale_shift', c_void_p), ('scale_shift_stride', c_int),
         ('out_stats', c_void_p), ('out_groups', c_int),
         ('x_bf16', c_int), ('y_bf16', c_int),
+        ('res', c_void_p), ('res_bf16', c_int),
     ]
 
 

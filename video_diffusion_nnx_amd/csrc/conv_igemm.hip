@@ -1020,6 +1020,10 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
         HookScope hs(mode, a, st, 4, a.Cout == 64 ? 64 : 128, 0, 0, a.kind == 1 ? a.H : a.H / 2);
         return launch_conv4x4_ws(a, st);
     }
+    if (conv1x1_pw_eligible(mode, a)) {                                      // 1x1 convs of the wide levels (bf16 tensors)
+        HookScope hs(mode, a, st, 5, conv1x1_pw_rows(a));
+        return launch_conv1x1_pw(a, st);
+    }
     {   // persistent specialisation for the level-0 shape (see conv64p_kernel)
         const int use64p = 1;
         const long tiles = (long)a.NF * (a.H / 16) * (a.W / 16);

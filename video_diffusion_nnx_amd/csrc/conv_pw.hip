@@ -1,0 +1,182 @@
+// Pointwise (1x1) convolution of the wide levels for bf16 tensors (gfx950, bf16 MFMA operands):
+//     y[p, :] = W . concat(x0[p, :], x1[p, :]) + b (+ res[p, :])
+// = the `res_conv` of ResnetBlocks (modules.py:219-222), the attention `to_out` projections (modules.py:312-326) and the
+// SpatialLinearAttention `to_out` (modules.py:121-129) of the levels with >= 128 channels in bf16 activation storage.
+//
+// The generic implicit-GEMM kernel stages a 256-pixel x 64-channel input tile in LDS per K chunk and synchronises the workgroup per
+// chunk: with ONE tap that is 16 MFMAs per wave between two barriers (10 launches of 84 us per step at B = 64, ~240 TFLOP/s, for
+// GEMMs that are HBM-bound at ~40 us).  Here the roles are those of the per-head attention kernels: a workgroup owns a tile of
+// output channels and keeps its weight rows [rows][Cin] RESIDENT in LDS for a whole range of pixels (persistent: one 8-wave
+// workgroup per CU); every wave walks its own groups of 32 pixels with no workgroup barrier: the x rows go from global memory
+// straight into MFMA B fragments (lane (pixel, q) = 16 bytes of a 64-byte K chunk; 8 loads of one K block are in flight while the 4 K
+// steps of the previous block are multiplied), weight fragments come from LDS and each feeds two MFMAs.  The weight image's rows are
+// permuted as in resblock_tail_rc16_kernel so that a lane's accumulators are whole 16-byte pieces (8 consecutive channels) of the
+// bf16 rows of y / res.  XCD-aware decode: the workgroups of the output-channel tiles of one pixel range are 8 ids apart (same XCD,
+// same L2), so x is fetched from HBM once.
+#include "vdx_common.h"
+#include "vdx_internal.h"
+
+namespace vdx {
+
+typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
+
+// ROWS output channels per workgroup (64 or 128); K = Cin is a multiple of 128 (K blocks of 4 steps of 32)
+template <int ROWS>
+__global__ __launch_bounds__(512) void conv1x1_pw_kernel(const ConvArgs P, const int nct, const int groups_per_range, const int ngroups) {
+    using M = Mma<MODE_BF16>;
+    constexpr int TM = ROWS / 16, TN = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Cin = P.C0 + P.C1, nkb = Cin >> 7;
+    const int WRS = Cin * 2 + 16;                          // LDS row stride of the weight image (bytes)
+    char* Wl = smem;                                       // [ROWS, A-tile order][WRS]
+    float* bl = reinterpret_cast<float*>(Wl + ROWS * WRS); // [ROWS] bias, channel order
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, q = lane >> 4;
+    const int ct = (blockIdx.x >> 3) % nct, range = ((blockIdx.x >> 3) / nct) * 8 + (blockIdx.x & 7);
+    const int co0 = ct * ROWS;
+    const int g0 = range * groups_per_range, g1 = min(g0 + groups_per_range, ngroups);
+    if (g0 >= g1) return;
+
+    {   // weight image: A-tile row (tm, r') = output channel co0 + (tm >> 1) * 32 + (r' >> 2) * 8 + (tm & 1) * 4 + (r' & 3)
+        const int cpr = Cin >> 3;                          // 16-byte pieces per row
+        const char* wsrc = reinterpret_cast<const char*>(P.wp);
+        for (int i = tid; i < ROWS * cpr; i += 512) {
+            const int row = i / cpr, c = i - row * cpr;
+            const int tm = row >> 4, rr = row & 15;
+            const int co = co0 + (tm >> 1) * 32 + (rr >> 2) * 8 + (tm & 1) * 4 + (rr & 3);
+            *reinterpret_cast<uint4*>(Wl + row * WRS + c * 16) = *reinterpret_cast<const uint4*>(wsrc + ((size_t)(P.wrow0 + co) * P.CinPad + c * 8) * 2);
+        }
+        for (int i = tid; i < ROWS; i += 512) bl[i] = P.bias ? P.bias[co0 + i] : 0.f;
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x0), 0, P.x0_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.C1 ? P.x1 : P.x0), 0, P.C1 ? P.x1_bytes : P.x0_bytes, 0x00020000);
+    const int nkb0 = P.C0 >> 7;                            // K blocks in x0 (C0 is a multiple of 128 when there is a second tensor)
+    const unsigned rb0 = P.C0 * 2, rb1 = P.C1 * 2;
+
+    // one K block (4 steps x TN pixel tiles) of B fragments: 8 buffer loads, all issued before the first use
+    auto load_block = [&](int g, int kb, pu32x4 (&xf)[4][TN]) {
+        const bool second = kb >= nkb0;                    // (uniform)
+        const unsigned rb = second ? rb1 : rb0;
+        const unsigned base = (unsigned)(g * 32 + lp) * rb + (unsigned)((second ? kb - nkb0 : kb) * 256 + q * 16);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) {
+                const unsigned off = base + tn * 16 * rb + s * 64;
+                xf[s][tn] = second ? __builtin_amdgcn_raw_buffer_load_b128(rx1, off, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rx0, off, 0, 0);
+            }
+    };
+    f32x4 acc[TM][TN];
+    auto mma_block = [&](int kb, const pu32x4 (&xf)[4][TN]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 bf[TN];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) bf[tn] = make_uint4(xf[s][tn].x, xf[s][tn].y, xf[s][tn].z, xf[s][tn].w);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                const uint4 af = *reinterpret_cast<const uint4*>(Wl + (tm * 16 + lp) * WRS + kb * 256 + s * 64 + q * 16);
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) M::mma(acc[tm][tn], af, bf[tn]);
+            }
+        }
+    };
+
+    char* const yb = reinterpret_cast<char*>(P.y);
+    const char* const resb = reinterpret_cast<const char*>(P.res);
+    // ROWS = 64: two fragment sets, the next K block's loads in flight during the MFMAs of the current one.  ROWS = 128 (64
+    // accumulator registers): one set -- the second would spill -- and the other wave of the SIMD covers the load latency
+    constexpr bool PP = ROWS == 64;
+    pu32x4 xa[4][TN], xb[PP ? 4 : 1][TN];
+    for (int g = g0 + wave; g < g1; g += 8) {
+        __asm__ volatile("" ::: "memory");                 // bias / weight fragments are re-read from LDS per group, not hoisted
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bl + (tm >> 1) * 32 + q * 8 + (tm & 1) * 4);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{b4.x, b4.y, b4.z, b4.w};
+        }
+        load_block(g, 0, xa);
+        if constexpr (PP) {
+            for (int kb = 0; kb < nkb; kb += 2) {
+                if (kb + 1 < nkb) load_block(g, kb + 1, xb);
+                mma_block(kb, xa);
+                if (kb + 1 >= nkb) break;
+                if (kb + 2 < nkb) load_block(g, kb + 2, xa);
+                mma_block(kb + 1, xb);
+            }
+        } else {
+            for (int kb = 0; kb < nkb; ++kb) {
+                mma_block(kb, xa);
+                if (kb + 1 < nkb) load_block(g, kb + 1, xa);
+            }
+        }
+        // epilogue: lane (pixel, q) holds channels co0 + 32 j + 8 q .. + 7 in acc[2 j][tn], acc[2 j + 1][tn]
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const size_t pix = (size_t)g * 32 + tn * 16 + lp;
+#pragma unroll
+            for (int j = 0; j < TM / 2; ++j) {
+                const size_t e = (pix * P.Cout + co0 + j * 32 + q * 8) * 2;
+                float o[8];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { o[k] = acc[2 * j][tn][k]; o[4 + k] = acc[2 * j + 1][tn][k]; }
+                if (resb) {
+                    const uint4 r = *reinterpret_cast<const uint4*>(resb + e);
+                    o[0] += __uint_as_float(r.x << 16); o[1] += __uint_as_float(r.x & 0xFFFF0000u);
+                    o[2] += __uint_as_float(r.y << 16); o[3] += __uint_as_float(r.y & 0xFFFF0000u);
+                    o[4] += __uint_as_float(r.z << 16); o[5] += __uint_as_float(r.z & 0xFFFF0000u);
+                    o[6] += __uint_as_float(r.w << 16); o[7] += __uint_as_float(r.w & 0xFFFF0000u);
+                }
+                *reinterpret_cast<uint4*>(yb + e) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+            }
+        }
+    }
+}
+
+int conv1x1_pw_rows(const ConvArgs& a) {
+    const int cin = a.C0 + a.C1;
+    // 128-row tiles when the weight image fits (rows x (2 Cin + 16) bytes <= ~136 KB) and Cout allows, else 64
+    if (a.Cout % 128 == 0 && (size_t)128 * (cin * 2 + 16) + 128 * 4 <= 140 * 1024) return 128;
+    return 64;
+}
+
+bool conv1x1_pw_eligible(int mode, const ConvArgs& a) {
+    if (mode != MODE_BF16 || a.kind != 0 || a.kh != 1 || a.kw != 1 || a.stride != 1 || a.pad != 0 || a.pro || a.out_stats) return false;
+    if (!a.x0_bf16 || (a.C1 && !a.x1_bf16) || !a.y_bf16 || (a.res && !a.res_bf16)) return false;
+    const int cin = a.C0 + a.C1;
+    if (cin % 128 || cin > 1024 || a.Cout % 64 || a.Cout < 128) return false;
+    if (a.C1 && (a.C0 % 128 || a.C1 % 128)) return false;
+    if (a.CinPad != cin) return false;
+    const size_t npix = (size_t)a.NF * a.H * a.W;
+    if (npix % 32 || npix < 32 * 256) return false;       // whole 32-pixel groups, enough of them for a chip of persistent workgroups
+    if (npix * (size_t)std::max(std::max(a.C0, a.C1), a.Cout) * 2 >= 0xFFFF0000ull) return false;
+    const int rows = conv1x1_pw_rows(a);
+    if ((size_t)rows * (cin * 2 + 16) + rows * 4 > 160 * 1024) return false;
+    return true;
+}
+
+hipError_t launch_conv1x1_pw(const ConvArgs& a, hipStream_t st) {
+    const int cin = a.C0 + a.C1, rows = conv1x1_pw_rows(a), nct = a.Cout / rows;
+    const int ngroups = (int)((size_t)a.NF * a.H * a.W / 32);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    // ranges: a multiple of 8 (XCD decode), ~ cus / nct of them, each a multiple of 8 groups (one per wave and pass)
+    int nranges = std::max(8, (cus / nct) / 8 * 8);
+    int gpr = ((ngroups + nranges - 1) / nranges + 7) / 8 * 8;
+    nranges = ((ngroups + gpr - 1) / gpr + 7) / 8 * 8;
+    const size_t lds = (size_t)rows * (cin * 2 + 16) + rows * 4;
+    auto go = [&](auto kfn) -> hipError_t {
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kfn, dim3(nranges * nct), dim3(512), lds, st, a, nct, gpr, ngroups);
+        return hipGetLastError();
+    };
+    return rows == 128 ? go(conv1x1_pw_kernel<128>) : go(conv1x1_pw_kernel<64>);
+}
+
+}  // namespace vdx

@@ -112,6 +112,11 @@ int vdx_conv_forward(int mode, const vdx_conv_desc* d, void* stream) {
     if ((d->x_bf16 || d->y_bf16) && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "conv: bf16 tensors need VDX_MODE_BF16");
     if (d->x_bf16 && (d->c0 % 8 || d->c1 % 8)) VDX_FAIL(VDX_ERR_INVALID, "conv: bf16 inputs need channel counts that are multiples of 8");
     a.x0_bf16 = a.x1_bf16 = d->x_bf16 ? 1 : 0; a.y_bf16 = d->y_bf16 ? 1 : 0;
+    if (d->res) {
+        if (d->out_stats || d->kind != 0 || d->stride != 1) VDX_FAIL(VDX_ERR_INVALID, "conv: res needs a stride-1 conv without statistics");
+        if (d->res_bf16 && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "conv: bf16 tensors need VDX_MODE_BF16");
+        a.res = (const float*)d->res; a.res_bf16 = d->res_bf16 ? 1 : 0;
+    }
     VDX_HIP(vdx::launch_conv(mode, a, (hipStream_t)stream));
     return VDX_OK;
 }

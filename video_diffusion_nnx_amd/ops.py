@@ -36,9 +36,9 @@ def gn_stats_reduce(stats: torch.Tensor, batch: int, groups: int) -> torch.Tenso
 
 def conv_forward(x0, packed_w, cout, *, mode, bias=None, x1=None, kind=0, k=3, stride=1,
                  in_stats=None, gamma=None, beta=None, groups=8, scale_shift=None,
-                 out_stats=None, out_groups=8, y_bf16=False) -> torch.Tensor:
+                 out_stats=None, out_groups=8, y_bf16=False, res=None) -> torch.Tensor:
     """x0: [B,F,H,W,C0] channel-last fp32 -- or bf16 (bf16 mode: bf16 activation storage) -- (x1 likewise, concatenated on
-    channels); y_bf16 selects a bf16 output tensor."""
+    channels); y_bf16 selects a bf16 output tensor; res: optional residual [B,F,H,W,cout] (fp32 or bf16) added to the output."""
     B, Fr, H, W, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[-1]
     if kind == 1:
@@ -58,6 +58,7 @@ def conv_forward(x0, packed_w, cout, *, mode, bias=None, x1=None, kind=0, k=3, s
     d.scale_shift = L.ptr(scale_shift)
     d.scale_shift_stride = 0 if scale_shift is None else scale_shift.shape[-1]
     d.out_stats, d.out_groups = L.ptr(out_stats), out_groups
+    d.res, d.res_bf16 = L.ptr(res), int(res is not None and res.dtype == torch.bfloat16)
     L.check(L.vdx_conv_forward(_mode(mode), C.byref(d), L.stream_ptr()))
     return y
 
