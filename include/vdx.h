@@ -314,7 +314,9 @@ int vdx_conv_backward_weights(const vdx_wgrad_desc* d, void* stream);
 /* Backward of act = SiLU((gamma*GroupNorm(y)+beta)*(1+s)+sh) and, when r != NULL, of out = act + LayerNorm_C(r)
  * (reference forward: modules.py:171-179,233-243).  dact/y/dy/r/dr channel-last [batch, pix_per_sample, c];
  * stats = the forward's GroupNorm statistics slab; scale_shift rows [s(c)|sh(c)] or NULL; d_gamma/d_beta/d_ln_* are
- * ACCUMULATED; dss [batch][2c] (ds|dsh) written when non-NULL; scratch >= batch*(2c + 2*groups) floats. */
+ * ACCUMULATED; dss [batch][2c] (ds|dsh) written when non-NULL; scratch >= vdx_norm_act_backward_scratch_floats(c, batch,
+ * pix_per_sample) floats, uninitialised (per-workgroup partial sums of the reduction pass + the per-group terms). */
+size_t vdx_norm_act_backward_scratch_floats(int c, int batch, long pix_per_sample);
 int vdx_norm_act_backward(const float* dact, const float* y, float* dy, const double* stats, const float* gamma, const float* beta,
                           int groups, const float* scale_shift, int scale_shift_stride, float* d_gamma, float* d_beta, float* dss,
                           const float* r, const float* ln_gamma, float* dr, float* d_ln_gamma, float* d_ln_beta, float* scratch,

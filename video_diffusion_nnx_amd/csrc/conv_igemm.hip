@@ -398,8 +398,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
 constexpr int C64_HALO = 18 * 18;
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + 16 * (chunk ^ (row & 7)); }
 
-// PRO / OUT16: prologue present, bf16 output -- compile-time, so the unused path costs no registers or issue slots
-template <bool IN16, bool PRO, bool OUT16>
+// PRO / OUT16 / RES: prologue present, bf16 output, residual epilogue (plain form only: the data gradient of a ResnetBlock's first
+// conv) -- compile-time, so the unused path costs no registers or issue slots
+template <bool IN16, bool PRO, bool OUT16, bool RES = false>
 __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
     using M = Mma<MODE_BF16>;
     constexpr int PCH = IN16 ? 8 : 4;                 // channels per 16-byte global piece
@@ -422,9 +423,10 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     if (t0 >= t1) return;
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x0), 0, P.x0_bytes, 0x00020000);
-    for (int i = tid; i < 9 * 64 * 8; i += 512) {     // packed [tap][co][64 ci] bf16: 128-byte rows already
-        const int row = i >> 3, c = i & 7;
-        *reinterpret_cast<uint4*>(Wl + swz(row, c)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) + (size_t)row * 128 + c * 16);
+    for (int i = tid; i < 9 * 64 * 8; i += 512) {     // packed [tap][wrows][64 ci] bf16: 128-byte rows; this conv's 64 rows start at wrow0
+        const int row = i >> 3, c = i & 7;            // (a slice of a wider packing: the data gradient of one half of a concat input)
+        const size_t srow = (size_t)(row >> 6) * P.wrows + P.wrow0 + (row & 63);
+        *reinterpret_cast<uint4*>(Wl + swz(row, c)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) + srow * 128 + c * 16);
     }
     if (tid < 128) chs[tid] = 0.0;
 
@@ -569,6 +571,17 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
         f32x4 acc[4][2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        // residual epilogue (the data gradient of a ResnetBlock's first conv: + the gradient of the skip path), plain form only:
+        // fetched before the MFMAs so that the epilogue does not wait for it
+        float4 rpre[RES ? 4 : 1][2];
+        if constexpr (RES) {
+            const int oy0 = tyc * 16 + 2 * wave, ox = txc * 16 + lp;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    rpre[tm][tn] = *reinterpret_cast<const float4*>(P.res + ((size_t)(fcur * P.H + oy0 + tn) * P.W + ox) * 64 + tm * 16 + 4 * q);   // fp32 res only: 8 plain loads, no format branch between them
+        }
         const char* At = Al + buf * (C64_HALO * 128);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -608,7 +621,8 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
                 const size_t gout = ((size_t)(fcur * P.H + oy0 + tn) * P.W + ox) * 64;
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm) {
-                    const float4 v = make_float4(acc[tm][tn][0] + bias4[tm].x, acc[tm][tn][1] + bias4[tm].y, acc[tm][tn][2] + bias4[tm].z, acc[tm][tn][3] + bias4[tm].w);
+                    float4 v = make_float4(acc[tm][tn][0] + bias4[tm].x, acc[tm][tn][1] + bias4[tm].y, acc[tm][tn][2] + bias4[tm].z, acc[tm][tn][3] + bias4[tm].w);
+                    if constexpr (RES) { const float4 r4 = rpre[tm][tn]; v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
                     store4_f32_or_bf16(P.y, gout + tm * 16 + 4 * q, v, OUT16 ? 1 : 0);
                     ssum[tm][0] += v.x; ssum[tm][1] += v.y; ssum[tm][2] += v.z; ssum[tm][3] += v.w;
                     ssq[tm][0] += v.x * v.x; ssq[tm][1] += v.y * v.y; ssq[tm][2] += v.z * v.z; ssq[tm][3] += v.w * v.w;
@@ -637,6 +651,10 @@ static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
         return hipGetLastError();
     };
     const int v = (a.x0_bf16 ? 4 : 0) | (a.pro ? 2 : 0) | (a.y_bf16 ? 1 : 0);
+    if (a.res) {
+        if (a.pro || !a.x0_bf16 || a.res_bf16) return hipErrorInvalidValue;      // (the fp32-input form with 32 more registers would spill)
+        return a.y_bf16 ? launch(conv64p_kernel<true, false, true, true>) : launch(conv64p_kernel<true, false, false, true>);
+    }
     switch (v) {
         case 0: return launch(conv64p_kernel<false, false, false>);
         case 1: return launch(conv64p_kernel<false, false, true>);
@@ -1028,7 +1046,7 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
         const int use64p = 1;
         const long tiles = (long)a.NF * (a.H / 16) * (a.W / 16);
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.C0 == 64 && a.C1 == 0 && a.Cout == 64 &&
-            a.wrows == 64 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
+            a.wrows >= 64 && a.wrow0 >= 0 && a.wrow0 + 64 <= a.wrows && (!a.res || (!a.pro && a.x0_bf16 && !a.res_bf16)) && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
             (!a.out_stats || (a.out_groups <= 32 && 64 % a.out_groups == 0))) {
             HookScope hs(mode, a, st, 1);
             return launch_conv64p(a, st);

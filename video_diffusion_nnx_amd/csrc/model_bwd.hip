@@ -124,7 +124,7 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     t.d_gamma = b.grads + r.b2_gs; t.d_beta = b.grads + r.b2_gb;
     t.r = rsrc; t.ln_gamma = b.p + r.n2_s; t.dr = L.t2; t.d_ln_gamma = b.grads + r.n2_s; t.d_ln_beta = b.grads + r.n2_b;
     // R at a fixed offset of the scratch: zeroed once per backward, the finalize pass leaves it zero again
-    t.G = b.normscr; t.R = b.normscr + (size_t)b.B * 64; t.r_clean = 1; t.C = r.cout; t.batch = b.B; t.pix_per_sample = b.pix(lvl);
+    t.G = b.normscr; t.R = b.normscr + (size_t)b.B * 64; t.C = r.cout; t.batch = b.B; t.pix_per_sample = b.pix(lvl);
     b.ok(launch_norm_bwd(t, b.writes(L.t1, L.t2)));
     // 2. conv2: y2 = conv(SiLU(GN1(y1)*(1+s)+sh)); the weight gradients that only need the tail's outputs go to the side stream now
     const float* ssrow = r.has_mlp ? b.ss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
@@ -137,7 +137,7 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     q.dact = L.t3; q.y = b.slot(r.s_y1); q.y_bf16 = (m->mode == MODE_BF16); q.dy = L.t4; q.dy_bf16 = d16; q.stats = b.stat(r.st1); q.gamma = b.p + r.b1_gs; q.beta = b.p + r.b1_gb; q.groups = G;
     q.ss = ssrow; q.ss_stride = 2 * r.cout; q.d_gamma = b.grads + r.b1_gs; q.d_beta = b.grads + r.b1_gb;
     q.dss = r.has_mlp ? b.dss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
-    q.G = b.normscr; q.R = b.normscr + (size_t)b.B * 64; q.r_clean = 1; q.C = r.cout; q.batch = b.B; q.pix_per_sample = b.pix(lvl);
+    q.G = b.normscr; q.R = b.normscr + (size_t)b.B * 64; q.C = r.cout; q.batch = b.B; q.pix_per_sample = b.pix(lvl);
     b.ok(launch_norm_bwd(q, b.writes(L.t4)));                                                           // t4 = dL/d(y1) (not t1: conv2's weight gradient may still be reading it)
     // 4. conv1 + residual branch
     wgrad(b, x0, c0, x1, c1, L.t4, r.cout, r.b1_w, r.b1_b, lvl, 0, 3, 1, nullptr, nullptr, nullptr, nullptr, 0, d16);
@@ -278,6 +278,17 @@ void bwd_state_free(BwdState* s) {
 
 static size_t al(size_t floats) { return (floats + 63) / 64 * 64; }
 
+// norm backward scratch: G [B][64] + the largest per-workgroup partials block of any level (norm_bwd.hip)
+static size_t norm_scratch_floats(const Model* m, int B) {
+    size_t mx = 0;
+    for (int l = 0; l < m->cfg.n_mults; ++l) {
+        const long s = m->cfg.image_size >> l, pix = (long)m->cfg.num_frames * s * s;
+        const int w0 = m->cfg.dim * m->cfg.dim_mults[l], w1 = l ? m->cfg.dim * m->cfg.dim_mults[l - 1] : m->init_dim;
+        for (int C : {w0, w1, m->cfg.dim}) mx = std::max(mx, norm_bwd_scratch_floats(C, B, pix));
+    }
+    return (size_t)B * 64 + mx;
+}
+
 size_t model_bwd_workspace_bytes(const Model* m, int B) {
     const int nl = m->cfg.n_mults;
     size_t fl = 0;
@@ -290,7 +301,7 @@ size_t model_bwd_workspace_bytes(const Model* m, int B) {
     fl += al(pix0 * (size_t)(m->cfg.attn_heads * 32) * 8);         // S
     fl += al((size_t)m->ss_floats_per_sample * B);                 // dss
     fl += al((size_t)m->temb_dim * B);                             // dtemb
-    fl += al((size_t)B * (2 * 1024 + 64));                         // norm scratch
+    fl += al(norm_scratch_floats(m, B));                           // norm scratch
     fl += al(sla_bwd_scratch_floats(B * m->cfg.num_frames, m->cfg.attn_heads));
     return fl * 4;
 }
@@ -338,7 +349,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
         b.S = w; w += al(pix0 * (size_t)(c.attn_heads * 32) * 8);
         b.dss = w; w += al((size_t)m->ss_floats_per_sample * B);
         b.dtemb = w; w += al((size_t)m->temb_dim * B);
-        b.normscr = w; w += al((size_t)B * (2 * 1024 + 64));
+        b.normscr = w; w += al(norm_scratch_floats(m, B));
         b.sla_a = w;
     }
     hipError_t e;
@@ -356,7 +367,6 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             VDX_E(hipMemsetAsync(grads, 0, (size_t)m->param_total * 4, st));
             VDX_E(hipMemsetAsync(b.dss, 0, (size_t)m->ss_floats_per_sample * B * 4, st));
             VDX_E(hipMemsetAsync(b.dtemb, 0, (size_t)m->temb_dim * B * 4, st));
-            VDX_E(hipMemsetAsync(b.normscr, 0, (size_t)B * (2 * 1024 + 64) * 4, st));
             // head: out = conv1x1(fin(concat(x_up, r)))
             const Level& U = m->ups[nl - 1];
             VDX_E(launch_final_conv_bwd(b.slot(m->fin.s_out), d_out, params + m->fin_w, b.lv[0].ga, grads + m->fin_w, grads + m->fin_b, pix0, c.dim, m->out_dim, b.writes(b.lv[0].ga)));

@@ -121,8 +121,11 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs P) {
             }
         }
     }
-    // ---- reduce over the workgroup's pixel lanes, then one atomic per (channel, quantity) ----
-    auto flush = [&](const float4& val, int c, float* dst0, int stride) {
+    // ---- reduce over the workgroup's pixel lanes, then ONE plain store per (channel, quantity) into this workgroup's row of the
+    //      partials [B][workgroups][4][C]; the finalize pass sums the rows.  (Round-2 first form: fp32 atomics onto one [B][C] row per
+    //      quantity -- contention-bound beyond ~64 workgroups per sample, so the pass ran on 192 workgroups, < 1 wave per SIMD, at
+    //      1.3-1.7 TB/s; without the atomics it runs on up to 256 workgroups per sample.) ----
+    auto flush = [&](const float4& val, int c, int qty) {
         __syncthreads();
         *reinterpret_cast<float4*>(red + tid * 4) = val;
         __syncthreads();
@@ -132,44 +135,80 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs P) {
                 const float4 u = *reinterpret_cast<const float4*>(red + (k * LPP + sub) * 4);
                 t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
             }
-            atomicAdd(dst0 + (size_t)(c + 0) * stride, t.x); atomicAdd(dst0 + (size_t)(c + 1) * stride, t.y);
-            atomicAdd(dst0 + (size_t)(c + 2) * stride, t.z); atomicAdd(dst0 + (size_t)(c + 3) * stride, t.w);
+            *reinterpret_cast<float4*>(P.R + ((((size_t)b * gridDim.x + blockIdx.x) * 4 + qty) * C + c)) = t;
         }
     };
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
         const int c = (v * LPP + sub) * 4;
-        flush(r0[v], c, P.R + (size_t)b * C * 2, 2);
-        flush(r1[v], c, P.R + (size_t)b * C * 2 + 1, 2);
-        if (P.r) { flush(g0[v], c, P.d_ln_gamma, 1); flush(g1[v], c, P.d_ln_beta, 1); }
+        flush(r0[v], c, 0);
+        flush(r1[v], c, 1);
+        if (P.r) { flush(g0[v], c, 2); flush(g1[v], c, 3); }
     }
 }
 
-// grid = batch.  Turns R into parameter gradients, (ds, dsh) and the per-group correction terms G[b][g][2].
-__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(NormBwdArgs P) {
+// grid = (channel tiles, batch).  Sums the reduce pass's per-workgroup partials in a fixed order and turns them into parameter
+// gradients, (ds, dsh) and the per-group correction terms G[b][g][2].  A workgroup owns CT channels = whole GroupNorm groups (CT is
+// a multiple of C / groups), so its groups' sums need nobody else; its 256 threads are CT channel lanes x 256 / CT slices of the
+// partial rows.  (With one workgroup per sample the pass took 78 us for 256 rows: 38 launches per train step.)
+__global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(NormBwdArgs P, int CT) {
     __shared__ float s1[32], s2[32];
-    const int tid = threadIdx.x, C = P.C, b = blockIdx.x;
+    __shared__ float red[4][256];
+    const int tid = threadIdx.x, C = P.C, b = blockIdx.y, nwg = P.nwg;
     const int cpg = C / P.groups;
+    const int c0 = blockIdx.x * CT, g0 = c0 / cpg, ngl = CT / cpg;       // first channel / first group / groups of this workgroup
     if (tid < 32) { s1[tid] = 0.f; s2[tid] = 0.f; }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        const float R0 = P.R[((size_t)b * C + c) * 2], R1 = P.R[((size_t)b * C + c) * 2 + 1];
-        *reinterpret_cast<float2*>(P.R + ((size_t)b * C + c) * 2) = make_float2(0.f, 0.f);      // leave the scratch clean for the next call
-        float sc = 1.f;
-        if (P.ss) sc = P.ss[(size_t)b * P.ss_stride + c] + 1.f;
-        const float ga = P.gamma[c], be = P.beta[c];
-        atomicAdd(P.d_gamma + c, sc * R1);
-        atomicAdd(P.d_beta + c, sc * R0);
-        if (P.dss) { P.dss[(size_t)b * 2 * C + c] = ga * R1 + be * R0; P.dss[(size_t)b * 2 * C + C + c] = R0; }
-        const int g = c / cpg;
-        atomicAdd(&s1[g], sc * ga * R0);
-        atomicAdd(&s2[g], sc * ga * R1);
+    const int CW = min(CT, 256), NS = 256 / CW;                         // channel lanes, row slices
+    const int cl = tid % CW, sl = tid / CW;
+    const int nq = P.r ? 4 : 2;
+    for (int cc = 0; cc < CT; cc += CW) {                                // (one trip unless a group is wider than 256 channels)
+        const int c = c0 + cc + cl;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool mine = c < C && cc + cl < CT;
+        if (sl < NS && mine) {
+            const float* p = P.R + (size_t)b * nwg * 4 * C + c;
+            // 4 rows (16 loads) in flight per thread: the rows were written by other XCDs a moment ago, every load is a trip to the
+            // memory side, and a plain row loop makes 8 dependent trips of it
+            for (int w = sl; w < nwg; w += 4 * NS) {
+                float t[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int wj = min(w + j * NS, nwg - 1);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) t[j][k] = (k < nq) ? p[((size_t)wj * 4 + k) * C] : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (w + j * NS < nwg) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) a[k] += t[j][k];
+                    }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[k][tid] = a[k];
+        __syncthreads();
+        if (sl == 0 && mine) {
+            float R0 = 0.f, R1 = 0.f, q0 = 0.f, q1 = 0.f;
+            for (int k = 0; k < NS; ++k) { R0 += red[0][k * CW + cl]; R1 += red[1][k * CW + cl]; q0 += red[2][k * CW + cl]; q1 += red[3][k * CW + cl]; }
+            float sc = 1.f;
+            if (P.ss) sc = P.ss[(size_t)b * P.ss_stride + c] + 1.f;
+            const float ga = P.gamma[c], be = P.beta[c];
+            atomicAdd(P.d_gamma + c, sc * R1);
+            atomicAdd(P.d_beta + c, sc * R0);
+            if (P.r) { atomicAdd(P.d_ln_gamma + c, q0); atomicAdd(P.d_ln_beta + c, q1); }
+            if (P.dss) { P.dss[(size_t)b * 2 * C + c] = ga * R1 + be * R0; P.dss[(size_t)b * 2 * C + C + c] = R0; }
+            const int gl = c / cpg - g0;
+            atomicAdd(&s1[gl], sc * ga * R0);
+            atomicAdd(&s2[gl], sc * ga * R1);
+        }
     }
     __syncthreads();
-    if (tid < P.groups) {
+    if (tid < ngl && g0 + tid < P.groups) {
         const float n = (float)((double)P.pix_per_sample * cpg);
-        P.G[((size_t)b * P.groups + tid) * 2] = s1[tid] / n;
-        P.G[((size_t)b * P.groups + tid) * 2 + 1] = s2[tid] / n;
+        P.G[((size_t)b * P.groups + g0 + tid) * 2] = s1[tid] / n;
+        P.G[((size_t)b * P.groups + g0 + tid) * 2 + 1] = s2[tid] / n;
     }
 }
 
@@ -252,6 +291,20 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs P) {
     }
 }
 
+// workgroups per sample of the reduce pass: every workgroup walks >= 2 passes of U pixels per lane group, at most 256 per sample
+static int norm_bwd_reduce_wgs(int C, long pix_per_sample) {
+    const int quads = C / 4;
+    int lpp = 1;
+    while (lpp < quads && lpp < 64) lpp <<= 1;
+    const int vpl = (quads + lpp - 1) / lpp, ppb = 256 / lpp, U = vpl == 1 ? 4 : 2;
+    return (int)std::max<long>(1, std::min<long>(256, (pix_per_sample + (long)ppb * U * 2 - 1) / ((long)ppb * U * 2)));
+}
+
+// floats of NormBwdArgs::R (+ G behind it): [B][workgroups][4][C] partials + [B][32 groups][2]
+size_t norm_bwd_scratch_floats(int C, int batch, long pix_per_sample) {
+    return (size_t)batch * norm_bwd_reduce_wgs(C, pix_per_sample) * 4 * C + (size_t)batch * 64;
+}
+
 hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st) {
     const int quads = a.C / 4;
     int lpp = 1;
@@ -259,15 +312,8 @@ hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st) {
     a.lpp = lpp;
     const int vpl = (quads + lpp - 1) / lpp;
     const int ppb = 256 / lpp;
-    // few, fat workgroups: every workgroup ends in 2..4 atomics per channel onto the same [B][C] rows (contention-bound beyond ~64)
-    // the reduce pass is a latency-bound stream (one pixel group in flight per lane group): enough workgroups to give every
-    // SIMD several waves, few enough that the per-workgroup table build and the 2C..4C atomics of the flush stay small
-    const int red_wgs = 192;
-    const int gx = (int)std::max<long>(1, std::min<long>((a.pix_per_sample + ppb - 1) / ppb, std::max(1, red_wgs / std::max(1, a.batch))));
-    if (!a.r_clean) {
-        hipError_t e = hipMemsetAsync(a.R, 0, (size_t)a.batch * a.C * 2 * 4, st);
-        if (e != hipSuccess) return e;
-    }
+    const int gx = norm_bwd_reduce_wgs(a.C, a.pix_per_sample);
+    a.nwg = gx;
     dim3 grid(gx, a.batch);
     switch (vpl) {
         case 1: hipLaunchKernelGGL(norm_bwd_reduce_kernel<1>, grid, dim3(256), 0, st, a); break;
@@ -275,7 +321,13 @@ hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st) {
         case 3: case 4: hipLaunchKernelGGL(norm_bwd_reduce_kernel<4>, grid, dim3(256), 0, st, a); break;
         default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(a.batch), dim3(256), 0, st, a);
+    {   // channel tile of the finalize pass: whole groups, >= 8 channels (<= 32 groups of it in LDS), at most 256
+        const int cpg = a.C / a.groups;
+        int ct = cpg;
+        while (ct < 8 && ct * 2 <= a.C && a.C % (ct * 2) == 0) ct *= 2;
+        if (a.C % ct || ct / cpg > 32) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3(a.C / ct, a.batch), dim3(256), 0, st, a, ct);
+    }
     const int gx2 = (int)std::max<long>(1, std::min<long>((a.pix_per_sample + ppb - 1) / ppb, 2048));
     dim3 grid2(gx2, a.batch);
     switch (vpl) {

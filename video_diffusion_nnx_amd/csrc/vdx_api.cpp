@@ -499,9 +499,14 @@ int vdx_norm_act_backward(const float* dact, const float* y, float* dy, const do
     a.dact = dact; a.y = y; a.dy = dy; a.stats = stats; a.gamma = gamma; a.beta = beta; a.groups = groups;
     a.ss = scale_shift; a.ss_stride = scale_shift_stride; a.d_gamma = d_gamma; a.d_beta = d_beta; a.dss = dss;
     a.r = r; a.ln_gamma = ln_gamma; a.dr = dr; a.d_ln_gamma = d_ln_gamma; a.d_ln_beta = d_ln_beta;
-    a.R = scratch; a.G = scratch + (size_t)batch * c * 2; a.C = c; a.batch = batch; a.pix_per_sample = pix_per_sample;
+    a.R = scratch; a.G = scratch + (vdx::norm_bwd_scratch_floats(c, batch, pix_per_sample) - (size_t)batch * 64); a.C = c; a.batch = batch; a.pix_per_sample = pix_per_sample;
     VDX_HIP(vdx::launch_norm_bwd(a, (hipStream_t)stream));
     return VDX_OK;
+}
+
+size_t vdx_norm_act_backward_scratch_floats(int c, int batch, long pix_per_sample) {
+    if (c < 4 || c % 4 || c > 1024 || batch < 1 || pix_per_sample < 1) return 0;
+    return vdx::norm_bwd_scratch_floats(c, batch, pix_per_sample);
 }
 
 int vdx_attention_core_backward(const float* qkv, const float* d_o, float* o, float* dq, float* dk, float* dv, int batch, int frames,

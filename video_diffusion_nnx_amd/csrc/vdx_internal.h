@@ -175,12 +175,13 @@ struct NormBwdArgs {
     float* d_gamma; float* d_beta;                                // accumulated (atomics)
     float* dss;                                                   // [B][2C] (ds | dsh) written, or null
     const float* r; const float* ln_gamma; float* dr; float* d_ln_gamma; float* d_ln_beta;   // LN branch (tail) or nulls
-    float* R; float* G;                                           // scratch: [B][C][2], [B][groups][2]
-    int r_clean;                                                  // R is already zero (the finalize pass leaves it zero again): no memset
+    float* R; float* G;                                           // scratch: per-workgroup partial sums [B][nwg][4][C] (written, never accumulated), [B][groups][2]
+    int nwg;                                                      // workgroups per sample of the reduce pass (completed by the launcher)
     int C, batch; long pix_per_sample;
     int lpp;
 };
 hipError_t launch_norm_bwd(NormBwdArgs a, hipStream_t st);
+size_t norm_bwd_scratch_floats(int C, int batch, long pix_per_sample);     // floats behind NormBwdArgs::R + G (G = R + that - 64 * batch)
 
 // attention core backward: qkv [npix][3*heads*32] (biased, q unscaled), dO [npix][heads*32] -> O, dq, dk, dv [npix][heads*32]
 struct AttnBwdArgs {

@@ -199,6 +199,9 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
 _norm_bwd = L._sig('vdx_norm_act_backward', C.c_int, [C.c_void_p] * 6 + [C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 9 + [C.c_int, C.c_int, C.c_long, C.c_void_p])
 
 
+_norm_bwd_scr = L._sig('vdx_norm_act_backward_scratch_floats', C.c_size_t, [C.c_int, C.c_int, C.c_long])
+
+
 def norm_act_backward(dact, y, stats, gamma, beta, groups=8, scale_shift=None, r=None, ln_gamma=None):
     """-> dict(dy, d_gamma, d_beta, dss, dr, d_ln_gamma, d_ln_beta)"""
     B, Cc = y.shape[0], y.shape[-1]
@@ -208,7 +211,7 @@ def norm_act_backward(dact, y, stats, gamma, beta, groups=8, scale_shift=None, r
     out = dict(dy=torch.empty_like(y), d_gamma=z(Cc), d_beta=z(Cc), dss=z(B, 2 * Cc) if scale_shift is not None else None,
                dr=torch.empty_like(y) if r is not None else None, d_ln_gamma=z(Cc) if r is not None else None,
                d_ln_beta=z(Cc) if r is not None else None)
-    scratch = z(B * (2 * Cc + 2 * groups))
+    scratch = torch.empty(_norm_bwd_scr(Cc, B, pix), dtype=torch.float32, device=dev)       # uninitialised on purpose: nothing accumulates into it
     L.check(_norm_bwd(L.ptr(dact), L.ptr(y), L.ptr(out['dy']), L.ptr(stats), L.ptr(gamma), L.ptr(beta), groups, L.ptr(scale_shift),
                       0 if scale_shift is None else scale_shift.shape[-1], L.ptr(out['d_gamma']), L.ptr(out['d_beta']), L.ptr(out['dss']),
                       L.ptr(r), L.ptr(ln_gamma), L.ptr(out['dr']), L.ptr(out['d_ln_gamma']), L.ptr(out['d_ln_beta']), L.ptr(scratch),
