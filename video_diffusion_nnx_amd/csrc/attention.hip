@@ -410,7 +410,9 @@ __global__ __launch_bounds__(256) void attention_reg_kernel(const AttnArgs P) {
 // nseq % 4 == 0 (the 4 sequences of a sub-tile share their outer index) and 32-bit per-thread offsets.
 // IO16: x and y are bf16 tensors (bf16 activation storage): pieces are 8 channels = 16 bytes, copied into the bf16 LDS tile
 // as they are, and the raw piece is the residual.
-template <int MODE, int NKT, int TMO, int TNO, bool IO16, bool F8>
+// FULL: sequences of exactly 16 tokens and C == the tile's channels -- no key mask, every piece valid (compile-time: the kernel is
+// vector-issue bound and the mask / validity selects are ~10 % of its VALU instructions)
+template <int MODE, int NKT, int TMO, int TNO, bool IO16, bool F8, bool FULL = false>
 __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, const int nsub) {
     using M = Mma<MODE>;
     static_assert(!IO16 || MODE == MODE_BF16, "bf16 activation storage implies bf16 MFMA operands");
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
         goff[u] = (unsigned)(sl * P.inner_stride + tok * P.tok_stride + c);
         xoff[u] = kt * PLANE + (sl * 16 + tok) * RS + pc * PCH * M::ES; // LDS row = sequence * 16 + token
         yoff[u] = (sl * 16 + tok) * RSY + c * 4;
-        pvalid[u] = tok < P.L && c < P.C;
+        pvalid[u] = FULL || (tok < P.L && c < P.C);
     }
     auto tile_base = [&](long sg0) -> long {                         // workgroup-uniform: scalar unit
         const unsigned inner = (unsigned)P.inner;
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
         const float4 b = *reinterpret_cast<const float4*>(P.bo + (cot0 + tmo) * 16 + 4 * q);
         bo[tmo] = f32x4{b.x, b.y, b.z, b.w};
     }
-    const bool masked = P.L < 16;
+    const bool masked = !FULL && P.L < 16;
 
     const long sg_first = (long)blockIdx.x * nsub * 4;
     fetch(sg_first);
@@ -551,9 +553,10 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
                 for (int r = 0; r < 4; ++r) if (4 * q + r >= P.L) sc[r] = -1e30f;
             }
             const float mx = max_q(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+            const float nmx = -mx * escale;            // exp2((s - max) * k) = exp2(fma(s, k, -max * k)): one FMA per score
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[r] = __builtin_amdgcn_exp2f((sc[r] - mx) * escale); sum += sc[r]; }
+            for (int r = 0; r < 4; ++r) { sc[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], escale, nmx)); sum += sc[r]; }
             const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
 #pragma unroll
             for (int r = 0; r < 4; ++r) sc[r] *= inv;
@@ -609,11 +612,11 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     }
 }
 
-template <int MODE, int NKT, int TMO, int TNO, bool IO16, bool F8 = false>
+template <int MODE, int NKT, int TMO, int TNO, bool IO16, bool F8 = false, bool FULL = false>
 static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
     using M = Mma<MODE>;
     const size_t lds = 2 * (size_t)NKT * 64 * ROW_STRIDE + (size_t)64 * (256 * M::ES + 16) + (size_t)64 * (NKT * M::KT * 4 + 16);
-    auto kfn = attention_h8_kernel<MODE, NKT, TMO, TNO, IO16, F8>;
+    auto kfn = attention_h8_kernel<MODE, NKT, TMO, TNO, IO16, F8, FULL>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -848,6 +851,8 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
                 if (a.C == 64 && nkt == 1) return launch_attn_h8_t<MODE, 1, 1, 2, false, true>(a, st);
                 if (a.C == 128 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 4, false, true>(a, st);
             }
+            if (a.io_bf16 && a.C == 64 && a.L == 16) return launch_attn_h8_t<MODE, 1, 1, 2, true, false, true>(a, st);
+            if (a.io_bf16 && a.C == 128 && a.L == 16) return launch_attn_h8_t<MODE, 2, 1, 4, true, false, true>(a, st);
             if (a.io_bf16 && a.C == 64) return launch_attn_h8_t<MODE, 1, 1, 2, true>(a, st);
             if (a.io_bf16 && a.C == 128) return launch_attn_h8_t<MODE, 2, 1, 4, true>(a, st);
         }

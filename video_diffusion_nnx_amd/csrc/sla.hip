@@ -616,12 +616,13 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[tm][tn][r]);
             mx = max_q(mx);
+            const float nmx = -mx * 1.44269504088896f;  // exp(a - max) = exp2(fma(a, log2 e, -max log2 e)): one FMA per element (vector-issue bound)
             float sum = 0.f;
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { acc[tm][tn][r] = __expf(acc[tm][tn][r] - mx); sum += acc[tm][tn][r]; }
-            const float inv = 1.0f / reduce_q(sum);
+                for (int r = 0; r < 4; ++r) { acc[tm][tn][r] = __builtin_amdgcn_exp2f(fmaf(acc[tm][tn][r], 1.44269504088896f, nmx)); sum += acc[tm][tn][r]; }
+            const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));     // v_rcp_f32 (1 ulp) instead of the IEEE division sequence
 #pragma unroll
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
