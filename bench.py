@@ -78,7 +78,7 @@ def conv_symbol(i):
     """rocprofv3's name of the kernel a vdx_conv_launch_info describes (template arguments as the profiler prints them)."""
     tf = lambda v: 'true' if v else 'false'
     if i.kernel == 1:
-        return f'vdx::conv64p_kernel<{tf(i.x_bf16)}, {tf(i.pro)}, {tf(i.y_bf16)}>'
+        return f'vdx::conv64p_kernel<{tf(i.x_bf16)}, {tf(i.pro)}, {tf(i.y_bf16)}, false>'       # <IN16, PRO, OUT16, RES>: RES (residual epilogue) only in the backward
     if i.kernel == 2:
         return 'vdx::conv128x64p_kernel'
     if i.kernel == 3:

@@ -14,6 +14,7 @@
 //   GEMM2  y[C, 64] += Wo[:, h*32:(h+1)*32] . O_h^T  (accumulated in registers across heads)
 // so q/k/v/scores never touch HBM: traffic = read x twice (GEMM1 + residual) + write y.
 #include "vdx_common.h"
+#include <type_traits>
 #include "vdx_internal.h"
 #include <stdlib.h>
 #include <algorithm>
@@ -425,8 +426,10 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     constexpr int NCHO = HD / KC;
     constexpr int CT = NKT * KT;                                      // channels held by the tile (== C)
     constexpr int RSY = CT * 4 + 16;
+    // one-barrier pipeline with double-buffered os / ys where the LDS allows it: bf16 operands, C <= 64 (the level-0 kernels: 123 KB)
+    constexpr bool PIPE = MODE == MODE_BF16 && NKT == 1;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // xs[2][NKT][64][RS] | os[64][RSO] | ys[64][RSY] (fp32)
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // xs[2][NKT][64][RS] | os[64][RSO] | ys[64][RSY] (fp32); PIPE: os, ys twice
     char* os = smem + 2 * BUF;
     char* ys = os + 64 * RSO;
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
@@ -447,12 +450,12 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
         yoff[u] = (sl * 16 + tok) * RSY + c * 4;
         pvalid[u] = FULL || (tok < P.L && c < P.C);
     }
-    auto tile_base = [&](long sg0) -> long {                         // workgroup-uniform: scalar unit
+    auto tile_base = [&](long sg0) __attribute__((always_inline)) -> long {                         // workgroup-uniform: scalar unit
         const unsigned inner = (unsigned)P.inner;
         return (long)((unsigned)sg0 / inner) * P.outer_stride + (long)((unsigned)sg0 % inner) * P.inner_stride;
     };
     float4 xpre[XP];                                   // IO16: the 16 raw bytes (8 bf16) travel in a float4
-    auto fetch = [&](long sg0) {
+    auto fetch = [&](long sg0) __attribute__((always_inline)) {
         const size_t xb = (size_t)tile_base(sg0);
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
             }
         }
     };
-    auto put = [&](char* xs) {
+    auto put = [&](char* xs) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             if (IO16 || MODE == MODE_F32) *reinterpret_cast<float4*>(xs + xoff[u]) = xpre[u];
@@ -516,18 +519,12 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     const bool masked = !FULL && P.L < 16;
 
     const long sg_first = (long)blockIdx.x * nsub * 4;
-    fetch(sg_first);
-    put(smem);
-    __syncthreads();
-    for (int sub = 0; sub < nsub; ++sub) {
-        const long sg0 = sg_first + (long)sub * 4;
-        if (sg0 >= P.nseq) break;                      // uniform across the workgroup
-        const char* xs = smem + (sub & 1) * BUF;
-        const bool more = (sub + 1 < nsub) && (sg0 + 4 < P.nseq);
-        float4 xcur[XP];                               // this sub-tile's fp32 rows = the residual of its output (no re-read)
-#pragma unroll
-        for (int u = 0; u < XP; ++u) xcur[u] = xpre[u];
-        if (more) fetch(sg0 + 4);
+    // ---- the three phases of a sub-tile ------------------------------------------------------------------------------------------
+    // (scalars of the argument block the phase lambdas use: captured as values, so that the block itself is not forced into scratch)
+    float* const y_out = P.y;
+    const int io16_rt = P.io_bf16, seq_len = P.L;
+    // A: per-head attention of the 4 sequences of the x tile `xs` -> os_w[row][h*32 + d]
+    auto phase_a = [&](const char* xs, char* os_w) __attribute__((always_inline)) {
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) {               // one sequence = one 16-row tile
             f32x4 aq[2], ak[2], av[2];
@@ -550,7 +547,7 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
             core_mma16<M, F8>(sc, ak[1], aq[1]);
             if (masked) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (4 * q + r >= P.L) sc[r] = -1e30f;
+                for (int r = 0; r < 4; ++r) if (4 * q + r >= seq_len) sc[r] = -1e30f;
             }
             const float mx = max_q(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
             const float nmx = -mx * escale;            // exp2((s - max) * k) = exp2(fma(s, k, -max * k)): one FMA per score
@@ -564,10 +561,12 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
             for (int t = 0; t < 2; ++t) {              // O^T[d, i] -> os[row i][h*32 + d]
                 f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
                 core_mma16<M, F8>(o, av[t], sc);
-                M::store4(os + (sl * 16 + lp) * RSO, h * D + t * 16 + 4 * q, make_float4(o[0], o[1], o[2], o[3]));
+                M::store4(os_w + (sl * 16 + lp) * RSO, h * D + t * 16 + 4 * q, make_float4(o[0], o[1], o[2], o[3]));
             }
         }
-        __syncthreads();
+    };
+    // B: out-projection of this wave's (output-channel tile, sequences) from os_r -> ys_w (fp32)
+    auto phase_b = [&](const char* os_r, char* ys_w) __attribute__((always_inline)) {
         f32x4 oacc[TMO][TNO];
 #pragma unroll
         for (int i = 0; i < TMO; ++i)
@@ -577,37 +576,88 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
         for (int ch = 0; ch < NCHO; ++ch) {
             uint4 bf[TNO];
 #pragma unroll
-            for (int tn = 0; tn < TNO; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(os + ((tn0 + tn) * 16 + lp) * RSO + ch * 64 + q * 16);
+            for (int tn = 0; tn < TNO; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(os_r + ((tn0 + tn) * 16 + lp) * RSO + ch * 64 + q * 16);
 #pragma unroll
             for (int tmo = 0; tmo < TMO; ++tmo)
 #pragma unroll
                 for (int tn = 0; tn < TNO; ++tn) M::mma(oacc[tmo][tn], wof[tmo][ch], bf[tn]);
         }
-        // out tile -> ys, then every wave stores whole 16-byte pieces in fetch order: coalesced, + residual from registers
 #pragma unroll
         for (int tmo = 0; tmo < TMO; ++tmo)
 #pragma unroll
             for (int tn = 0; tn < TNO; ++tn)
-                *reinterpret_cast<f32x4*>(ys + ((tn0 + tn) * 16 + lp) * RSY + ((cot0 + tmo) * 16 + 4 * q) * 4) = oacc[tmo][tn];
-        if (more) put(smem + ((sub + 1) & 1) * BUF);
-        __syncthreads();
+                *reinterpret_cast<f32x4*>(ys_w + ((tn0 + tn) * 16 + lp) * RSY + ((cot0 + tmo) * 16 + 4 * q) * 4) = oacc[tmo][tn];
+    };
+    // C: every wave stores whole 16-byte pieces of the sub-tile at sg0 in fetch order: coalesced, + residual (the fetched rows)
+    auto phase_c = [&](const char* ys_r, long sg0, const float4 (&xres)[XP]) __attribute__((always_inline)) {
         const size_t yb = (size_t)tile_base(sg0);
 #pragma unroll
         for (int u = 0; u < XP; ++u) {
             if (!pvalid[u]) continue;
-            const float4 o4 = *reinterpret_cast<const float4*>(ys + yoff[u]);
+            const float4 o4 = *reinterpret_cast<const float4*>(ys_r + yoff[u]);
             if (IO16) {
-                const float4 o5 = *reinterpret_cast<const float4*>(ys + yoff[u] + 16);
-                const unsigned r0 = __float_as_uint(xcur[u].x), r1 = __float_as_uint(xcur[u].y), r2 = __float_as_uint(xcur[u].z), r3 = __float_as_uint(xcur[u].w);
+                const float4 o5 = *reinterpret_cast<const float4*>(ys_r + yoff[u] + 16);
+                const unsigned r0 = __float_as_uint(xres[u].x), r1 = __float_as_uint(xres[u].y), r2 = __float_as_uint(xres[u].z), r3 = __float_as_uint(xres[u].w);
                 uint4 w;
                 w.x = pack_bf16x2(o4.x + __uint_as_float(r0 << 16), o4.y + __uint_as_float(r0 & 0xFFFF0000u));
                 w.y = pack_bf16x2(o4.z + __uint_as_float(r1 << 16), o4.w + __uint_as_float(r1 & 0xFFFF0000u));
                 w.z = pack_bf16x2(o5.x + __uint_as_float(r2 << 16), o5.y + __uint_as_float(r2 & 0xFFFF0000u));
                 w.w = pack_bf16x2(o5.z + __uint_as_float(r3 << 16), o5.w + __uint_as_float(r3 & 0xFFFF0000u));
-                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(P.y) + (yb + goff[u]) * 2) = w;
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(y_out) + (yb + goff[u]) * 2) = w;
             } else {
-                store4_f32_or_bf16(P.y, yb + goff[u], make_float4(o4.x + xcur[u].x, o4.y + xcur[u].y, o4.z + xcur[u].z, o4.w + xcur[u].w), P.io_bf16);
+                store4_f32_or_bf16(y_out, yb + goff[u], make_float4(o4.x + xres[u].x, o4.y + xres[u].y, o4.z + xres[u].z, o4.w + xres[u].w), io16_rt);
             }
+        }
+    };
+
+    // number of sub-tiles this workgroup walks (uniform)
+    const long left = (P.nseq - sg_first + 3) / 4;
+    const int nv = (int)(left < (long)nsub ? (left > 0 ? left : 0) : (long)nsub);
+    if (nv <= 0) return;
+    fetch(sg_first);
+    put(smem);
+    __syncthreads();
+    if constexpr (PIPE) {
+        // ---- software pipeline over sub-tiles, ONE barrier per sub-tile: in iteration `it` the workgroup stores tile it - 2 (C),
+        //      runs the attention of tile it (A) and the out-projection of tile it - 1 (B); os and ys are double-buffered, so
+        //      the three phases touch different buffers and a wave that is late in one phase does not park the others twice per tile
+        //      (two-barrier form: 44 % of wave life parked at barriers / waits at level 0, rocprofv3 PMC) ----
+        char* const os2[2] = {os, os + 64 * RSO};
+        char* const ys2[2] = {os + 2 * 64 * RSO, os + 2 * 64 * RSO + 64 * RSY};
+        float4 xres[2][XP];
+        auto iter = [&](int it, auto parc) __attribute__((always_inline)) {
+            constexpr int PAR = decltype(parc)::value;  // it & 1
+            if (it >= 2 && it - 2 < nv) phase_c(ys2[PAR], sg_first + (long)(it - 2) * 4, xres[PAR]);
+            const bool do_a = it < nv, more = it + 1 < nv;
+            if (do_a) {
+#pragma unroll
+                for (int u = 0; u < XP; ++u) xres[PAR][u] = xpre[u];
+                if (more) fetch(sg_first + (long)(it + 1) * 4);
+                phase_a(smem + PAR * BUF, os2[PAR]);
+            }
+            if (it >= 1 && it - 1 < nv) phase_b(os2[PAR ^ 1], ys2[PAR ^ 1]);
+            if (do_a && more) put(smem + (PAR ^ 1) * BUF);
+            __syncthreads();
+        };
+        for (int it = 0; it < nv + 2; it += 2) {
+            iter(it, std::integral_constant<int, 0>{});
+            if (it + 1 < nv + 2) iter(it + 1, std::integral_constant<int, 1>{});
+        }
+    } else {
+        for (int sub = 0; sub < nv; ++sub) {
+            const long sg0 = sg_first + (long)sub * 4;
+            const char* xs = smem + (sub & 1) * BUF;
+            const bool more = sub + 1 < nv;
+            float4 xcur[XP];                           // this sub-tile's fp32 rows = the residual of its output (no re-read)
+#pragma unroll
+            for (int u = 0; u < XP; ++u) xcur[u] = xpre[u];
+            if (more) fetch(sg0 + 4);
+            phase_a(xs, os);
+            __syncthreads();
+            phase_b(os, ys);
+            if (more) put(smem + ((sub + 1) & 1) * BUF);
+            __syncthreads();
+            phase_c(ys, sg0, xcur);
         }
     }
 }
@@ -615,7 +665,8 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
 template <int MODE, int NKT, int TMO, int TNO, bool IO16, bool F8 = false, bool FULL = false>
 static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
     using M = Mma<MODE>;
-    const size_t lds = 2 * (size_t)NKT * 64 * ROW_STRIDE + (size_t)64 * (256 * M::ES + 16) + (size_t)64 * (NKT * M::KT * 4 + 16);
+    constexpr int NBUF = (MODE == MODE_BF16 && NKT == 1) ? 2 : 1;     // PIPE (see the kernel): os and ys double-buffered
+    const size_t lds = 2 * (size_t)NKT * 64 * ROW_STRIDE + NBUF * ((size_t)64 * (256 * M::ES + 16) + (size_t)64 * (NKT * M::KT * 4 + 16));
     auto kfn = attention_h8_kernel<MODE, NKT, TMO, TNO, IO16, F8, FULL>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
