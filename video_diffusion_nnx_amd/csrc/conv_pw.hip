@@ -164,10 +164,13 @@ hipError_t launch_conv1x1_pw(const ConvArgs& a, hipStream_t st) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
     // ranges: a multiple of 8 (XCD decode), ~ cus / nct of them, each a multiple of 8 groups (one per wave and pass)
-    int nranges = std::max(8, (cus / nct) / 8 * 8);
+    const size_t lds = (size_t)rows * (cin * 2 + 16) + rows * 4;
+    // two workgroups per CU when the weight image allows it (<= 80 KB, and the 128-row form needs < 128 registers): the kernel waits on
+    // memory for most of a wave's life (79 % parked with one workgroup per CU, rocprofv3 PMC), so more waves = more loads in flight
+    const int wg_per_cu = (lds <= 80 * 1024 && rows == 128) ? 2 : 1;
+    int nranges = std::max(8, (cus * wg_per_cu / nct) / 8 * 8);
     int gpr = ((ngroups + nranges - 1) / nranges + 7) / 8 * 8;
     nranges = ((ngroups + gpr - 1) / gpr + 7) / 8 * 8;
-    const size_t lds = (size_t)rows * (cin * 2 + 16) + rows * 4;
     auto go = [&](auto kfn) -> hipError_t {
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -542,8 +542,10 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
     constexpr int NCHO = HD / KC;
     constexpr bool WO_RES = (TMO * NCHO <= 16);        // to_out fragments register-resident
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // xs[2][NKT][64][RS] | os[64][RSO]
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // xs[2][NKT][64][RS] | os[64][RSO] | IO16: ys[64][RSY] (fp32)
     char* os = smem + 2 * T::BUF;
+    constexpr int RSY = NKT * M::KT * 4 + 16;
+    char* ys = os + 64 * RSO;
     const int tid = threadIdx.x, lane = tid & 63, h = tid >> 6;
     const int lp = lane & 15, q = lane >> 4;
     const int n = blockIdx.x / P.nchunk, chunk = blockIdx.x % P.nchunk;
@@ -589,6 +591,11 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
         if (r0 >= P.N) break;
         const char* xs = smem + (sub & 1) * T::BUF;
         const bool more = (sub + 1 < P.nsub) && (r0 + 64 < P.N);
+        float4 xcur[IO16 ? T::XP : 1];                  // IO16: this sub-tile's raw bf16 pieces = the residual of its output (no re-read)
+        if (IO16) {
+#pragma unroll
+            for (int u = 0; u < T::XP; ++u) xcur[u] = t.xpre[u];
+        }
         if (more) t.fetch(P.x, xbase, IO16 ? 1 : P.io_bf16, r0 + 64, P.N, P.C, tid);
         // q[d, n] of this head: lane (lp, q) = (pixel lp, channels 4q+r)
         f32x4 acc[2][4];
@@ -659,20 +666,50 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
                 for (int tn = 0; tn < TNO; ++tn) M::mma(oacc[tmo][tn], a, bf[tn]);
             }
         }
+        if constexpr (IO16) {
+            // bf16 tensors: the out tile goes through LDS (ys, fp32) so that every thread stores ONE whole 16-byte piece in fetch order
+            // (1 KB contiguous per wave instruction) with the residual taken from the fetched piece in registers.  (First form: each
+            // lane loaded the 8 residual bytes of its 4 channels right before storing 8 bytes -- a dependent L2 / HBM round trip per
+            // tile in the epilogue and 32-byte row fragments per instruction: 52 % of wave life parked.)
 #pragma unroll
-        for (int tmo = 0; tmo < TMO; ++tmo) {
-            const int co = (cot0 + tmo) * 16 + 4 * q;
+            for (int tmo = 0; tmo < TMO; ++tmo)
 #pragma unroll
-            for (int tn = 0; tn < TNO; ++tn) {
-                const int row = r0 + (tn0 + tn) * 16 + lp;
-                if (row >= P.N) continue;
-                const float4 xr = load4_f32_or_bf16(P.x, xbase + (size_t)row * P.C + co, IO16 ? 1 : P.io_bf16);
-                store4_f32_or_bf16(P.y, xbase + (size_t)row * P.C + co,
-                                   make_float4(oacc[tmo][tn][0] + xr.x, oacc[tmo][tn][1] + xr.y, oacc[tmo][tn][2] + xr.z, oacc[tmo][tn][3] + xr.w), IO16 ? 1 : P.io_bf16);
+                for (int tn = 0; tn < TNO; ++tn)
+                    *reinterpret_cast<f32x4*>(ys + ((tn0 + tn) * 16 + lp) * RSY + ((cot0 + tmo) * 16 + 4 * q) * 4) = oacc[tmo][tn];
+            if (more) t.put(smem + ((sub + 1) & 1) * T::BUF, tid);
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < T::XP; ++u) {
+                const int i = tid + 512 * u;
+                const int kt = i / (64 * T::APIECES), rem = i % (64 * T::APIECES);
+                const int row = rem / T::APIECES, c = kt * M::KT + (rem % T::APIECES) * 8;
+                if (r0 + row >= P.N || c >= P.C) continue;
+                const float4 o4 = *reinterpret_cast<const float4*>(ys + row * RSY + c * 4), o5 = *reinterpret_cast<const float4*>(ys + row * RSY + c * 4 + 16);
+                const unsigned x0 = __float_as_uint(xcur[u].x), x1 = __float_as_uint(xcur[u].y), x2 = __float_as_uint(xcur[u].z), x3 = __float_as_uint(xcur[u].w);
+                uint4 w;
+                w.x = pack_bf16x2(o4.x + __uint_as_float(x0 << 16), o4.y + __uint_as_float(x0 & 0xFFFF0000u));
+                w.y = pack_bf16x2(o4.z + __uint_as_float(x1 << 16), o4.w + __uint_as_float(x1 & 0xFFFF0000u));
+                w.z = pack_bf16x2(o5.x + __uint_as_float(x2 << 16), o5.y + __uint_as_float(x2 & 0xFFFF0000u));
+                w.w = pack_bf16x2(o5.z + __uint_as_float(x3 << 16), o5.w + __uint_as_float(x3 & 0xFFFF0000u));
+                *reinterpret_cast<uint4*>(reinterpret_cast<char*>(P.y) + (xbase + (size_t)(r0 + row) * P.C + c) * 2) = w;
             }
+            // (the next iteration writes ys only after its own first barrier, which every wave reaches after these reads)
+        } else {
+#pragma unroll
+            for (int tmo = 0; tmo < TMO; ++tmo) {
+                const int co = (cot0 + tmo) * 16 + 4 * q;
+#pragma unroll
+                for (int tn = 0; tn < TNO; ++tn) {
+                    const int row = r0 + (tn0 + tn) * 16 + lp;
+                    if (row >= P.N) continue;
+                    const float4 xr = load4_f32_or_bf16(P.x, xbase + (size_t)row * P.C + co, P.io_bf16);
+                    store4_f32_or_bf16(P.y, xbase + (size_t)row * P.C + co,
+                                       make_float4(oacc[tmo][tn][0] + xr.x, oacc[tmo][tn][1] + xr.y, oacc[tmo][tn][2] + xr.z, oacc[tmo][tn][3] + xr.w), P.io_bf16);
+                }
+            }
+            if (more) t.put(smem + ((sub + 1) & 1) * T::BUF, tid);
+            __syncthreads();
         }
-        if (more) t.put(smem + ((sub + 1) & 1) * T::BUF, tid);
-        __syncthreads();
     }
 }
 
@@ -899,7 +936,7 @@ static hipError_t launch_sla8_t(const SlaArgs& a, hipStream_t st) {
     using M = Mma<MODE>;
     using T = SlaTile<MODE, NKT, IO16>;
     const size_t lds_ctx = 2 * (size_t)T::BUF;
-    const size_t lds_out = lds_ctx + (size_t)64 * (256 * M::ES + 16);
+    const size_t lds_out = lds_ctx + (size_t)64 * (256 * M::ES + 16) + (IO16 ? (size_t)64 * (NKT * M::KT * 4 + 16) : 0);
     auto kc = sla_ctx8_kernel<MODE, NKT, IO16>;
     auto ko = sla_out8_kernel<MODE, NKT, TMO, TNO, IO16>;
     hipError_t e;
