@@ -292,6 +292,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs P) {
 }
 
 // workgroups per sample of the reduce pass: every workgroup walks >= 2 passes of U pixels per lane group, at most 256 per sample
+// (measured at the N shape, B = 4: 128 per sample 55 us per launch, 256: 49-50, 512: 50)
 static int norm_bwd_reduce_wgs(int C, long pix_per_sample) {
     const int quads = C / 4;
     int lpp = 1;
