@@ -85,6 +85,8 @@ def conv_symbol(i):
         return f'vdx::conv3x3_ws_kernel<{i.geo}, {tf(i.pro)}>'
     if i.kernel == 4:
         return f'vdx::conv4x4_ws_kernel<{i.geo}, {2 if i.kind == 1 else 1}, {i.bc}>'
+    if i.kernel == 6:
+        return f'vdx::conv64d_kernel<{tf(i.y_bf16)}, false>'                  # <OUT16, RES>: bf16-input, prologue-free form of conv64p (LDS-DMA staging)
     if i.kernel == 5:
         return f'vdx::conv1x1_pw_kernel<{i.bc}>'
     return f'vdx::conv_igemm_kernel<{i.mode}, {i.bc}, 2, {i.nw}, {i.inf}>'

@@ -93,7 +93,7 @@ int vdx_conv_forward(int mode, const vdx_conv_desc* d, void* stream);
  * a caller can bracket each launch with its own events on `stream` while the real step runs.  NULL disables.  Not for use while
  * a stream is being captured into a graph (run the loop with use_graph = 0). */
 typedef struct {
-    int kernel;                   /* 0 conv_igemm_kernel, 1 conv64p_kernel, 2 conv128x64p_kernel, 3 conv3x3_ws_kernel, 4 conv4x4_ws_kernel, 5 conv1x1_pw_kernel<bc> */
+    int kernel;                   /* 0 conv_igemm_kernel, 1 conv64p_kernel, 2 conv128x64p_kernel, 3 conv3x3_ws_kernel, 4 conv4x4_ws_kernel, 5 conv1x1_pw_kernel<bc>, 6 conv64d_kernel */
     int mode, bc, nw, inf;        /* conv_igemm template arguments <mode, BC, 2, NW, INF> */
     int geo, pro;                 /* conv3x3_ws <GEO, PRO>; conv4x4_ws <GEO, 1 + kind, bc>; conv64p <IN16, PRO, OUT16> uses x_bf16 / pro / y_bf16 */
     int x_bf16, y_bf16;

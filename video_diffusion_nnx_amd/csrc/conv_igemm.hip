@@ -636,6 +636,193 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     flush_stats(bcur);
 }
 
+// ---- the same persistent 64 -> 64 conv for bf16 INPUT tensors, input staged by LDS-DMA ("conv64d") -------------------------------
+// conv64p_kernel fetches the next tile into registers (24 VGPRs of staging + per-piece LDS offsets), waits for them half way
+// through the tap loop, applies the prologue and writes the tile with ds_write_b128; its prologue form sits on the 256-register limit
+// with a 60-byte spill and 39 % of its wave life is spent parked (rocprofv3 PMC, profiles/r02_pmc_step.md).  Here the next tile lands
+// in the other LDS buffer by global_load_lds (lane l fetches the chunk that belongs at its swizzled position, out-of-image pieces
+// read a zero page: conv128x64p_kernel's scheme) -- no staging registers, no LDS store instructions.  Plain form only (no prologue;
+// optional residual epilogue): 254 -> 245 us per launch at B = 64.  The prologue form was built the same way (every thread
+// transforming the pieces it issued in place behind counted vmcnt waits, coefficients in registers) and measured SLOWER than the
+// register-staged conv64p_kernel (340 vs 323 us: the in-place pass adds a ds_read_b128 per piece and its waits), so it is not kept.
+constexpr int C64D_AROWS = 328;                       // 324 halo rows padded to 41 DMA instructions of 8 rows
+constexpr int C64D_APL = C64D_AROWS * 128;
+__device__ __attribute__((aligned(16))) unsigned g_zero_page_c64d[4];
+
+template <bool OUT16, bool RES>
+__global__ __launch_bounds__(512) void conv64d_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
+    using M = Mma<MODE_BF16>;
+    constexpr int NDMA = 41, NK = (NDMA + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Wl = smem;                                  // [9 * 64 rows][128 B]
+    char* Al = Wl + 9 * 64 * 128;                     // [2][328 rows][128 B]
+    double* chs = reinterpret_cast<double*>(Al + 2 * C64D_APL);   // [2][64] channel sum / sumsq of the current sample (f64: order-independent)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int lp = lane & 15, q = lane >> 4;
+    const int tiles_x = P.W >> 4, tiles_pf = tiles_x * (P.H >> 4);
+    const int t0 = blockIdx.x * tiles_per_block, t1 = min(t0 + tiles_per_block, total_tiles);
+    if (t0 >= t1) return;
+
+    for (int i = tid; i < 9 * 64 * 8; i += 512) {     // packed [tap][wrows][64 ci] bf16: 128-byte rows; this conv's 64 rows start at wrow0
+        const int row = i >> 3, c = i & 7;
+        const size_t srow = (size_t)(row >> 6) * P.wrows + P.wrow0 + (row & 63);
+        *reinterpret_cast<uint4*>(Wl + swz(row, c)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) + srow * 128 + c * 16);
+    }
+    if (tid < 128) chs[tid] = 0.0;
+
+    // DMA pieces of this lane: instruction u = wave + 8 k covers halo rows 8 u .. 8 u + 7; the lane's row is 8 u + (lane >> 3) and its
+    // 16 bytes are global chunk cch = (lane & 7) ^ (lane >> 3) of that row -- the same 8 channels for every piece of the lane
+    int pyx[NK];                                      // (halo row << 5) | halo column; row 100 = padding row / no instruction
+    const int cch = (lane & 7) ^ (lane >> 3);
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        const int u = wave + 8 * k, hp = u * 8 + (lane >> 3);
+        pyx[k] = (((u < NDMA && hp < C64_HALO) ? hp / 18 : 100) << 5) | (hp % 18);
+    }
+    const char* const zero_page = reinterpret_cast<const char*>(g_zero_page_c64d);
+    const char* const xb = reinterpret_cast<const char*>(P.x0);
+    const unsigned al_base = lds_addr(Al);
+    auto decode = [&](int t, int& f, int& ty, int& tx) { f = t / tiles_pf; const int r = t - f * tiles_pf; ty = r / tiles_x; tx = r - ty * tiles_x; };
+    auto dma = [&](int t, int buf) {
+        int f, ty, tx; decode(t, f, ty, tx);
+        const unsigned dst = al_base + buf * C64D_APL + wave_u * 1024;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            if (wave_u + 8 * k >= NDMA) continue;     // (uniform)
+            const int gy = ty * 16 - 1 + (pyx[k] >> 5), gx = tx * 16 - 1 + (pyx[k] & 31);
+            const bool ok = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+            const size_t off = (size_t)((f * P.H + gy) * P.W + gx) * 128 + cch * 16;
+            glds16(ok ? static_cast<const void*>(xb + off) : static_cast<const void*>(zero_page), dst + k * 8 * 1024);
+        }
+    };
+    f32x4 ssum[4], ssq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ssum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    auto flush_stats = [&](int b) {
+        if (!P.out_stats) return;
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s1 = reduce16(ssum[tm][e]), s2 = reduce16(ssq[tm][e]);
+                if (lp == 0) { unsafeAtomicAdd(&chs[tm * 16 + 4 * q + e], (double)s1); unsafeAtomicAdd(&chs[64 + tm * 16 + 4 * q + e], (double)s2); }
+                ssum[tm][e] = 0.f; ssq[tm][e] = 0.f;
+            }
+        __syncthreads();
+        const int cpg = 64 / P.out_groups;
+        if (tid < 2 * P.out_groups) {
+            const int g = tid >> 1, which = tid & 1;
+            double t = 0.0;
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) t += chs[which * 64 + c];
+            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * P.out_groups + g) * 2 + which, t);
+        }
+        __syncthreads();
+        if (tid < 128) chs[tid] = 0.0;
+        __syncthreads();
+    };
+
+    int hpb[2];
+    hpb[0] = (2 * wave) * 18 + lp; hpb[1] = hpb[0] + 18;
+    float4 bias4[4];
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) bias4[tm] = P.bias ? *reinterpret_cast<const float4*>(P.bias + tm * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    int fcur, tyc, txc;
+    decode(t0, fcur, tyc, txc);
+    int bcur = fcur / P.F;
+    __syncthreads();                                  // weights + chs visible
+    dma(t0, 0);
+    wait_vm<0>();
+    __syncthreads();
+    for (int t = t0; t < t1; ++t) {
+        const int buf = (t - t0) & 1;
+        const bool more = t + 1 < t1;
+        int fn = fcur, tyn = tyc, txn = txc, bn = bcur;
+        if (more) {
+            decode(t + 1, fn, tyn, txn);
+            bn = fn / P.F;
+            dma(t + 1, buf ^ 1);                      // the other buffer was last read during tile t - 1 (barrier since)
+        }
+        f32x4 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        float4 rpre[RES ? 4 : 1][2];
+        if constexpr (RES) {                          // (fp32 residual: issued after the DMA, so the waits below cover it)
+            const int oy0 = tyc * 16 + 2 * wave, ox = txc * 16 + lp;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+                    rpre[tm][tn] = *reinterpret_cast<const float4*>(P.res + ((size_t)(fcur * P.H + oy0 + tn) * P.W + ox) * 64 + tm * 16 + 4 * q);
+        }
+        const char* At = Al + buf * C64D_APL;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int dy = tap / 3, dx = tap % 3;
+            int boff[2];
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) { const int hp = hpb[tn] + dy * 18 + dx; boff[tn] = swz(hp, q); }
+            const int woff = swz(tap * 64 + lp, q);
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                uint4 af[4], bf[2];
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) af[tm] = *reinterpret_cast<const uint4*>(Wl + ((woff + tm * 16 * 128) ^ (ch * 64)));
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(At + (boff[tn] ^ (ch * 64)));
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
+            }
+        }
+        wait_vm<0>();                                 // the next tile has landed (before the stores below: the wait covers the DMA only)
+        {
+            const int oy0 = tyc * 16 + 2 * wave, ox = txc * 16 + lp;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const size_t gout = ((size_t)(fcur * P.H + oy0 + tn) * P.W + ox) * 64;
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) {
+                    float4 v = make_float4(acc[tm][tn][0] + bias4[tm].x, acc[tm][tn][1] + bias4[tm].y, acc[tm][tn][2] + bias4[tm].z, acc[tm][tn][3] + bias4[tm].w);
+                    if constexpr (RES) { const float4 r4 = rpre[tm][tn]; v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
+                    store4_f32_or_bf16(P.y, gout + tm * 16 + 4 * q, v, OUT16 ? 1 : 0);
+                    ssum[tm][0] += v.x; ssum[tm][1] += v.y; ssum[tm][2] += v.z; ssum[tm][3] += v.w;
+                    ssq[tm][0] += v.x * v.x; ssq[tm][1] += v.y * v.y; ssq[tm][2] += v.z * v.z; ssq[tm][3] += v.w * v.w;
+                }
+            }
+        }
+        if (more && bn != bcur) { flush_stats(bcur); bcur = bn; }    // uniform: the next tile belongs to another sample
+        fcur = fn; tyc = tyn; txc = txn;
+        __syncthreads();                              // next tile landed everywhere; everybody is done reading this one
+    }
+    flush_stats(bcur);
+}
+
+static hipError_t launch_conv64d(const ConvArgs& a, hipStream_t st) {
+    const int total = a.NF * (a.H >> 4) * (a.W >> 4);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const int grid = std::min(total, cus);
+    const int tpb = (total + grid - 1) / grid;
+    const int nblocks = (total + tpb - 1) / tpb;
+    const size_t lds = 9 * 64 * 128 + 2 * (size_t)C64D_APL + 128 * 8;
+    auto launch = [&](auto kfn) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(512), lds, st, a, tpb, total);
+        return hipGetLastError();
+    };
+    if (a.pro || !a.x0_bf16) return hipErrorInvalidValue;
+    if (a.res) {
+        if (a.res_bf16) return hipErrorInvalidValue;
+        return a.y_bf16 ? launch(conv64d_kernel<true, true>) : launch(conv64d_kernel<false, true>);
+    }
+    return a.y_bf16 ? launch(conv64d_kernel<true, false>) : launch(conv64d_kernel<false, false>);
+}
+
 static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
     const int total = a.NF * (a.H >> 4) * (a.W >> 4);
     int dev = 0, cus = 256;
@@ -1048,8 +1235,9 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.C0 == 64 && a.C1 == 0 && a.Cout == 64 &&
             a.wrows >= 64 && a.wrow0 >= 0 && a.wrow0 + 64 <= a.wrows && (!a.res || (!a.pro && a.x0_bf16 && !a.res_bf16)) && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
             (!a.out_stats || (a.out_groups <= 32 && 64 % a.out_groups == 0))) {
-            HookScope hs(mode, a, st, 1);
-            return launch_conv64p(a, st);
+            const bool dma_form = a.x0_bf16 && !a.pro;               // bf16 input, no prologue: input staged by LDS-DMA (conv64d_kernel)
+            HookScope hs(mode, a, st, dma_form ? 6 : 1);
+            return dma_form ? launch_conv64d(a, st) : launch_conv64p(a, st);
         }
         const bool in16c = a.x0_bf16 && (!a.C1 || a.x1_bf16);
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.Cout == 64 && in16c && !a.pro &&
