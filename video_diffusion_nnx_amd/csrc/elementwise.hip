@@ -635,16 +635,28 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(TimeMlpArgs P) {
     }
     __syncthreads();
     for (int n = tid; n < P.time_dim; n += 256) {
-        float acc = P.b1[n];
-        for (int k = 0; k < P.dim; ++k) acc = fmaf(emb[k], P.w1[(size_t)k * P.time_dim + n], acc);
-        h[n] = gelu_tanh_f(acc);
+        // four independent partial sums, eight weight loads in flight: the kernel is one dependent chain per output otherwise
+        // (36 us per step for 0.3 MFLOP at B = 64)
+        float a0 = P.b1[n], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+        for (int k = 0; k < P.dim; k += 4) {
+            const float w0 = P.w1[(size_t)k * P.time_dim + n], w1 = P.w1[(size_t)(k + 1) * P.time_dim + n];
+            const float w2 = P.w1[(size_t)(k + 2) * P.time_dim + n], w3 = P.w1[(size_t)(k + 3) * P.time_dim + n];
+            a0 = fmaf(emb[k], w0, a0); a1 = fmaf(emb[k + 1], w1, a1); a2 = fmaf(emb[k + 2], w2, a2); a3 = fmaf(emb[k + 3], w3, a3);
+        }
+        h[n] = gelu_tanh_f((a0 + a1) + (a2 + a3));
     }
     __syncthreads();
     float* out = P.temb + (size_t)b * P.temb_dim;
     for (int n = tid; n < P.time_dim; n += 256) {
-        float acc = P.b2[n];
-        for (int k = 0; k < P.time_dim; ++k) acc = fmaf(h[k], P.w2[(size_t)k * P.time_dim + n], acc);
-        out[n] = acc;
+        float a0 = P.b2[n], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 2
+        for (int k = 0; k < P.time_dim; k += 4) {
+            const float w0 = P.w2[(size_t)k * P.time_dim + n], w1 = P.w2[(size_t)(k + 1) * P.time_dim + n];
+            const float w2 = P.w2[(size_t)(k + 2) * P.time_dim + n], w3 = P.w2[(size_t)(k + 3) * P.time_dim + n];
+            a0 = fmaf(h[k], w0, a0); a1 = fmaf(h[k + 1], w1, a1); a2 = fmaf(h[k + 2], w2, a2); a3 = fmaf(h[k + 3], w3, a3);
+        }
+        out[n] = (a0 + a1) + (a2 + a3);
     }
     if (P.cond_dim) {
         const bool use_null = P.cond_mask ? (P.cond_mask[b] != 0) : (P.null_all != 0);
@@ -684,7 +696,8 @@ __global__ __launch_bounds__(256) void resblock_ss_lin_kernel(const float* __res
     for (int j = 0; j < SS_BG; ++j) acc[j] = 0.f;
     const int kper = (temb_dim + 3) / 4, k0 = kq * kper, k1 = min(temb_dim, k0 + kper);
     if (n < N)
-        for (int k = k0; k < k1; ++k) {
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) {              // (unrolled: eight weight loads in flight instead of one dependent trip per k)
             const float w = W[(size_t)k * N + n];
 #pragma unroll
             for (int j = 0; j < SS_BG; ++j) acc[j] = fmaf(act[j * temb_dim + k], w, acc[j]);   // rows past nb hold stale LDS: never stored

@@ -169,7 +169,7 @@ int vdx_final_conv(const float* x, const float* kernel, const float* bias, float
 int vdx_time_mlp(const int* time, const float* w1, const float* b1, const float* w2, const float* b2, int dim,
                  const float* cond, const float* null_cond_emb, const unsigned char* cond_mask, int null_all, int cond_dim,
                  float* temb, int batch, void* stream) {
-    if (!time || !w1 || !b1 || !w2 || !b2 || !temb || dim < 4 || (dim & 1)) VDX_FAIL(VDX_ERR_INVALID, "time_mlp: bad argument");
+    if (!time || !w1 || !b1 || !w2 || !b2 || !temb || dim < 4 || (dim % 4)) VDX_FAIL(VDX_ERR_INVALID, "time_mlp: bad argument (dim must be a multiple of 4)");
     if (cond_dim && (!cond || !null_cond_emb)) VDX_FAIL(VDX_ERR_INVALID, "time_mlp: cond missing");
     vdx::TimeMlpArgs a;
     memset(&a, 0, sizeof(a));
