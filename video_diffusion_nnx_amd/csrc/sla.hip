@@ -518,6 +518,20 @@ __global__ __launch_bounds__(512) void sla_ctx8_kernel(const SlaArgs P) {
         if (more) t.put(smem + ((sub + 1) & 1) * T::BUF, tid);
         __syncthreads();
     }
+    if (P.nchunk == 1) {
+        // the frame is one chunk (many frames: B = 64): this wave holds the whole context of (frame, head) -- normalise and write
+        // ctxT[n][h][e][d] here, no partials and no combine launch
+        char* ct = reinterpret_cast<char*>(P.ctxT) + (size_t)(n * P.heads + h) * 32 * 32 * M::ES;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const float inv = 1.0f / s_run[dt];
+#pragma unroll
+            for (int et = 0; et < 2; ++et)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) M::store1(ct + (size_t)(et * 16 + 4 * q + r) * 32 * M::ES, dt * 16 + lp, cacc[et][dt][r] * inv);
+        }
+        return;
+    }
     float* part = P.part + ((size_t)(n * P.nchunk + chunk) * P.heads + h) * SLA_PART;
 #pragma unroll
     for (int et = 0; et < 2; ++et)
@@ -944,8 +958,10 @@ static hipError_t launch_sla8_t(const SlaArgs& a, hipStream_t st) {
     if (lds_out > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(ko), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_out)) != hipSuccess) return e;
     hipLaunchKernelGGL(kc, dim3(a.NF * a.nchunk), dim3(512), lds_ctx, st, a);
     if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(sla_combine_kernel<MODE>, dim3(a.NF * a.heads), dim3(256), 0, st, a.part, a.ctxT, a.nchunk, a.heads);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (a.nchunk > 1) {                                       // (one chunk per frame: sla_ctx8_kernel wrote ctxT itself)
+        hipLaunchKernelGGL(sla_combine_kernel<MODE>, dim3(a.NF * a.heads), dim3(256), 0, st, a.part, a.ctxT, a.nchunk, a.heads);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(ko, dim3(a.NF * a.nchunk), dim3(512), lds_out, st, a);
     return hipGetLastError();
 }
