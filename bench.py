@@ -202,7 +202,7 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=40)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=int(os.environ.get('VDX_BENCH_BATCH', 64)), help='videos per GPU (the sampling batch is free; end of round 1: 32 -> 37.4, 48 -> 37.7, 64 -> 38.5, 128 -> 37.8 frames/s on one box)')
+    ap.add_argument('--batch', type=int, default=int(os.environ.get('VDX_BENCH_BATCH', 64)), help='videos per GPU (the sampling batch is free; end of round 2 on one box: 64 -> 45.5, 96 -> 46.3, 128 -> 46.6 frames/s)')
     ap.add_argument('--mode', default=os.environ.get('VDX_BENCH_MODE', 'bf16'), choices=['bf16', 'f32'])
     ap.add_argument('--dim', type=int, default=64)
     ap.add_argument('--frames', type=int, default=16)
