@@ -23,105 +23,27 @@ sys.path.insert(0, ROOT)
 T_STEPS = 1000
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense peaks, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILES = ('r02_traffic.json', 'r01_traffic.json')        # newest first
+TRAFFIC_FILES = ('r03_traffic.json',)        # newest first; keyed by 'kernel | shape' (tools/traffic.sh)
 
 
-def conv_layers(dim, mults, frames, size, batch):
-    """Every conv_igemm launch of one UNet forward: (Cin, Cout, H, taps, out_pixels_per_sample_frame, kind)."""
-    dims = [dim] + [dim * m for m in mults]
-    nl = len(mults)
-    L = []
-
-    def res(cin, cout, s):
-        L.append((cin, cout, s, 9, 'c3'))
-        L.append((cout, cout, s, 9, 'c3p'))
-        if cin != cout:
-            L.append((cin, cout, s, 1, 'c1'))
-    for i in range(nl):
-        s = size >> i
-        res(dims[i], dims[i + 1], s); res(dims[i + 1], dims[i + 1], s)
-        if i < nl - 1:
-            L.append((dims[i + 1], dims[i + 1], s, 16, 'down'))
-    s = size >> (nl - 1)
-    res(dims[nl], dims[nl], s); res(dims[nl], dims[nl], s)
-    for i in range(nl):
-        din, dout = dims[nl - 1 - i], dims[nl - i]
-        s = size >> (nl - 1 - i)
-        res(2 * dout, din, s); res(din, din, s)
-        if i < nl - 1:
-            L.append((din, din, s, 16, 'up'))
-    res(2 * dim, dim, size)
-    return L
-
-
-def conv_flops(layer, frames, batch):
-    cin, cout, s, taps, kind = layer
-    if kind == 'down':
-        pix = (s // 2) ** 2
-        return 2.0 * batch * frames * pix * cin * cout * 16
-    if kind == 'up':
-        return 2.0 * batch * frames * (2 * s) ** 2 * cin * cout * 4          # 4 effective taps per output (SURVEY 8d)
-    return 2.0 * batch * frames * s * s * cin * cout * taps
-
-
-def conv_bytes(layer, frames, batch, mode, act='f32'):
-    """Algorithmic HBM bytes of one conv launch: input + output tensors in their storage type (fp32, or bf16 with bf16
-    activation storage) + packed weights (SURVEY 8d op-level definition)."""
-    cin, cout, s, taps, kind = layer
-    so = s // 2 if kind == 'down' else (2 * s if kind == 'up' else s)
-    es = 2 if mode == 'bf16' else 4
-    ea = 2.0 if act == 'bf16' else 4.0
-    return ea * batch * frames * (s * s * cin + so * so * cout) + es * taps * cin * cout
-
-
-def conv_symbol(i):
-    """rocprofv3's name of the kernel a vdx_conv_launch_info describes (template arguments as the profiler prints them)."""
-    tf = lambda v: 'true' if v else 'false'
-    if i.kernel == 1:
-        return f'vdx::conv64p_kernel<{tf(i.x_bf16)}, {tf(i.pro)}, {tf(i.y_bf16)}, false>'       # <IN16, PRO, OUT16, RES>: RES (residual epilogue) only in the backward
-    if i.kernel == 2:
-        return 'vdx::conv128x64p_kernel'
-    if i.kernel == 3:
-        return f'vdx::conv3x3_ws_kernel<{i.geo}, {tf(i.pro)}>'
-    if i.kernel == 4:
-        return f'vdx::conv4x4_ws_kernel<{i.geo}, {2 if i.kind == 1 else 1}, {i.bc}>'
-    if i.kernel == 6:
-        return f'vdx::conv64d_kernel<{tf(i.y_bf16)}, false>'                  # <OUT16, RES>: bf16-input, prologue-free form of conv64p (LDS-DMA staging)
-    if i.kernel == 5:
-        return f'vdx::conv1x1_pw_kernel<{i.bc}>'
-    return f'vdx::conv_igemm_kernel<{i.mode}, {i.bc}, 2, {i.nw}, {i.inf}>'
-
-
-def conv_info_work(i, mode):
-    """(FLOPs, algorithmic HBM bytes) of one conv launch: input + output tensors in their storage type + packed weights
-    (SURVEY 8d op-level definition; ConvTranspose = 4 effective taps per output pixel)."""
-    es = 2.0 if mode == 'bf16' else 4.0
-    ein, eout = (2.0 if i.x_bf16 else 4.0), (2.0 if i.y_bf16 else 4.0)
-    if i.kind == 1:
-        ho, wo, eff = 2 * i.h, 2 * i.w, 4
-    else:
-        ho, wo, eff = -(-i.h // i.stride), -(-i.w // i.stride), i.taps
-    flops = 2.0 * i.nf * ho * wo * i.cin * i.cout * eff
-    nbytes = ein * i.nf * i.h * i.w * i.cin + eout * i.nf * ho * wo * i.cout + es * i.taps * i.cin * i.cout
-    return flops, nbytes
-
-
-def time_convs_in_step(run_eager, dev, mode, steps=3):
-    """Roofline leg: HIP-event duration of every convolution launch INSIDE the real denoising step.  The library calls a hook
-    before / after each conv launch (vdx_set_conv_launch_hook, include/vdx.h); the hook records a torch event on the launch
-    stream, so each launch of `steps` eager (not graph-replayed) steps of the timed region's own loop is bracketed by its own pair.
+def time_kernels_in_step(run_eager, dev, steps=3):
+    """Roofline leg: HIP-event duration of EVERY kernel launch INSIDE the real denoising step.  The library calls a hook before /
+    after each launch (vdx_set_launch_hook, include/vdx.h) with the kernel's name, its template arguments + operand shape and the
+    algorithmic FLOPs / bytes of that launch; the hook records a torch event on the launch stream, so each launch of `steps` eager
+    (not graph-replayed) steps of the timed region's own loop is bracketed by its own pair.  Records are keyed by (kernel, shape):
+    one symbol serves several levels of the network and its per-launch time differs 4x between them.
     Why not a stand-alone replay: back-to-back repetitions of one MFMA + HBM-heavy shape on random data run 25-80 % above the
-    same kernel's duration inside the step (rocprofv3 traces of both; the level-0 conv: 265 us in the step, 330-500 us replayed,
-    350 us on all-zero data) -- sustained identical launches pull the clocks down in a way the step's kernel mix does not."""
+    same kernel's duration inside the step (rocprofv3 traces of both) -- sustained identical launches pull the clocks down in a
+    way the step's kernel mix does not.
+    Returns (per_key: {(kernel, shape): {ms, flops, bytes, launches}} per step, sequence of one step, event overhead in us)."""
     import ctypes as C
     import torch
     from video_diffusion_nnx_amd import _lib as L
 
     class Info(C.Structure):
-        _fields_ = [(n, C.c_int) for n in ('kernel', 'mode', 'bc', 'nw', 'inf', 'geo', 'pro', 'x_bf16', 'y_bf16',
-                                           'cin', 'cout', 'h', 'w', 'nf', 'taps', 'kind', 'stride')]
+        _fields_ = [('kernel', C.c_char_p), ('shape', C.c_char_p), ('flops', C.c_double), ('bytes', C.c_double)]
     HOOK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(Info), C.c_void_p)
-    set_hook = L._sig('vdx_set_conv_launch_hook', None, [HOOK, C.c_void_p])
+    set_hook = L._sig('vdx_set_launch_hook', None, [HOOK, C.c_void_p])
     st = torch.cuda.current_stream(dev)
     records, open_ev = [], []
 
@@ -132,8 +54,7 @@ def time_convs_in_step(run_eager, dev, mode, steps=3):
             open_ev.append(e)
         else:
             i = info.contents
-            snap = Info(*[getattr(i, n) for n, _ in Info._fields_])
-            records.append((snap, open_ev.pop(), e))
+            records.append((i.kernel.decode(), i.shape.decode(), i.flops, i.bytes, open_ev.pop(), e))
     cb = HOOK(hook)
     run_eager(1)                                       # eager path warm-up (first-call attributes), not recorded
     torch.cuda.synchronize(dev)
@@ -151,27 +72,20 @@ def time_convs_in_step(run_eager, dev, mode, steps=3):
         torch.cuda.synchronize(dev)
     finally:
         set_hook(C.cast(None, HOOK), None)
-    per_symbol = {}
-    if os.environ.get('VDX_BENCH_CONV_DETAIL'):                      # per-shape table on stderr (diagnostics)
-        shapes = {}
-        for info, e0, e1 in records:
-            k = (conv_symbol(info), info.cin, info.cout, info.h, info.taps, info.kind, info.stride, info.pro)
-            v = shapes.setdefault(k, [0, 0.0, conv_info_work(info, mode)[0]])
-            v[0] += 1; v[1] += max(e0.elapsed_time(e1) - overhead_ms, 0.0)
-        for k, (n, ms, fl) in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-            log(f'  {k[0][5:46]:42s} cin {k[1]:4d} cout {k[2]:4d} h {k[3]:3d} taps {k[4]:2d} kind {k[5]} s {k[6]} pro {k[7]}: '
-                f'{n // steps:2d}/step x {ms / n * 1e3:7.1f} us  {fl / (ms / n * 1e-3) / 1e12:6.0f} TF')
-    for info, e0, e1 in records:
-        fl, by = conv_info_work(info, mode)
-        d = per_symbol.setdefault(conv_symbol(info), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+    per_key = {}
+    for k, sh, fl, by, e0, e1 in records:
+        d = per_key.setdefault((k, sh), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
         d['ms'] += max(e0.elapsed_time(e1) - overhead_ms, 0.0) / steps; d['flops'] += fl / steps; d['bytes'] += by / steps; d['launches'] += 1
-    for d in per_symbol.values():
+    for d in per_key.values():
         d['launches'] = d['launches'] // steps
-    return per_symbol, overhead_ms * 1e3
+    n = len(records) // steps
+    sequence = [{'kernel': k, 'shape': sh, 'flops': fl, 'bytes': by} for k, sh, fl, by, _, _ in records[:n]]
+    return per_key, sequence, overhead_ms * 1e3
 
 
-def cpu_baseline(dim, frames, size, budget_s=20.0):
-    """CPU restatement (PyTorch-CPU, NOT JAX) of the same UNet forward at B=1, timed on this node's host cores."""
+def cpu_baseline(dim, frames, size, budget_s=20.0, train=True):
+    """CPU restatement (PyTorch-CPU, NOT JAX) of the same UNet forward at B=1, timed on this node's host cores; `train`: one
+    p_losses forward + backward of the restatement (torch autograd) beside it."""
     import torch
     from oracle import unet3d_ref as R
     cfg = R.UnetConfig(dim=dim, channels=1)
@@ -186,8 +100,18 @@ def cpu_baseline(dim, frames, size, budget_s=20.0):
         while n < 3 or (time.time() - t0 < budget_s and n < 10):
             R.unet_forward(p, cfg, x, t); n += 1
         dt = (time.time() - t0) / n
-    return dict(value=frames / (T_STEPS * dt), unit='frames/s', cores=cores, kind='port',
-                sample=f'{n} Unet3D forwards (B=1, fp32, oracle/unet3d_ref.py on torch-CPU, {dt*1e3:.0f} ms each) extrapolated x{T_STEPS} steps')
+    out = dict(value=frames / (T_STEPS * dt), unit='frames/s', cores=cores, kind='port',
+               sample=f'{n} Unet3D forwards (B=1, fp32, oracle/unet3d_ref.py on torch-CPU, {dt*1e3:.0f} ms each) extrapolated x{T_STEPS} steps')
+    if train:
+        leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        noise = torch.randn(1, frames, size, size, 1)
+        t0 = time.time()
+        loss = ((R.unet_forward(leaves, cfg, x, t) - noise) ** 2).mean()
+        torch.autograd.grad(loss, list(leaves.values()), allow_unused=True)
+        dtt = time.time() - t0
+        out['train'] = dict(value=1.0 / dtt, unit='samples/s', cores=cores, kind='port',
+                            sample=f'1 l2 p_losses forward + backward (B=1, fp32, torch autograd through oracle/unet3d_ref.py, {dtt*1e3:.0f} ms), no optimizer step')
+    return out
 
 
 def log(msg):
@@ -212,7 +136,10 @@ def parse_args(argv=None):
     ap.add_argument('--attn-fp8', action='store_true', help='bf16 mode: fp8 (e4m3) QK^T / PV in the <= 16-token attention blocks (BASELINE configs[4]); off by default')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-y-shape', action='store_true', help='skip the secondary timing of the YAML-literal config_v2_2 (dim 32, 10 frames)')
+    ap.add_argument('--launch-seq', default='', help='write the (kernel, shape, flops, bytes) sequence of one denoising step to this JSON file (tools/shape_table.py joins it with a rocprofv3 kernel trace)')
     ap.add_argument('--no-train', action='store_true', help='skip the training leg (p_losses fwd+bwd, bucketed all-reduce, Adam/EMA)')
+    ap.add_argument('--comm', default=os.environ.get('VDX_COMM', 'torch'), choices=['torch', 'abi'], help="gradient all-reduce of the training leg: torch.distributed (RCCL under 'nccl') or the communicator behind the C ABI (vdx_allreduce_bucket)")
     ap.add_argument('--train-batch', type=int, default=4, help='training samples per GPU (BASELINE.json configs[2]: 4)')
     ap.add_argument('--train-steps', type=int, default=10)
     return ap.parse_args(argv)
@@ -248,6 +175,7 @@ def train_leg(args, dev, world, rank):
     unet = Unet3D(dim=args.dim, rngs=0, channels=1, mode=args.mode, device=dev)
     gd = GaussianDiffusion(unet, image_size=S, num_frames=Fr, channels=1, timesteps=T_STEPS, loss_type='l2')
     tmp = tempfile.mkdtemp(prefix=f'vdx_bench_r{rank}_')
+    T.Trainer.comm_backend = args.comm
     tr = T.Trainer(gd, tmp, dataset_path='synthetic:8', train_batch_size=B * world, train_num_steps=10 ** 9, results_folder=tmp)
     g = torch.Generator().manual_seed(1000 + rank)                # S2 of SURVEY 8d: x0 ~ U[0,1), seed 1000 + rank
     x = torch.rand(B, 1, Fr, S, S, generator=g).to(dev)
@@ -273,22 +201,85 @@ def train_leg(args, dev, world, rank):
     ms = timed(args.train_steps, 3)
     exposed = 0.0
     if world > 1:
-        reducer_cls = T.GradBucketReducer
-        class _NoComm(reducer_cls):                               # same step, gradient all-reduce switched off (timing only)
-            def __init__(self, *a, **k):
-                super().__init__(*a, **k)
-                self.enabled = False
-        T.GradBucketReducer = _NoComm
+        tr.comm_enabled = False                                   # same step, gradient all-reduce switched off (timing only)
         try:
             timed(2, 100)
             ms_nocomm = timed(args.train_steps, 102)
         finally:
-            T.GradBucketReducer = reducer_cls
+            tr.comm_enabled = True
         exposed = max(0.0, ms - ms_nocomm)
     n_buckets = len(tr.buckets)
     return {'samples_per_s': world * B / (ms * 1e-3), 'ms_per_step': ms, 'batch_per_gpu': B, 'global_batch': B * world,
-            'allreduce_exposed_ms': exposed, 'grad_bytes': int(unet.flat_params.numel()) * 4, 'buckets': n_buckets,
+            'allreduce_exposed_ms': exposed, 'comm': args.comm, 'grad_bytes': int(unet.flat_params.numel()) * 4, 'buckets': n_buckets,
             'what': 'q_sample + Unet3D fwd (fp32 activation storage) + l2 loss + staged backward + bucketed sum all-reduce + Adam + EMA'}
+
+
+def sampling_leg(args, dev, world, rank, dim, Fr, S, B, steps, warmup, roofline):
+    """K graph-replayed reverse-diffusion steps of a dim / Fr x S x S network at batch B on this rank, bracketed by barrier +
+    synchronize on both sides, max over ranks.  Returns (ms_per_step, act, roofline records or None)."""
+    import torch
+    import torch.distributed as dist
+    from video_diffusion_nnx_amd import _lib as L
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion, vdx_p_sample_loop
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    unet = Unet3D(dim=dim, rngs=0, channels=1, mode=args.mode, device=dev, attn_fp8=args.attn_fp8)
+    gd = GaussianDiffusion(unet, image_size=S, num_frames=Fr, channels=1, timesteps=T_STEPS, loss_type='l2')
+    h = unet.handle(Fr, S)
+    act = args.act_storage if args.act_storage != 'auto' else ('bf16' if args.mode == 'bf16' else 'f32')
+    unet.act_bf16 = (act == 'bf16')
+    unet.apply_activation_storage(h)
+    ws = unet.workspace(B, Fr, S)
+    stream = torch.cuda.Stream(device=dev)
+    rec = None
+    with torch.cuda.stream(stream):
+        img = gd.randn((B, 1, Fr, S, S), 1000 + rank, 0)
+        eps = torch.empty(B, Fr, S, S, 1, device=dev)
+        t_dev = torch.full((B,), T_STEPS - 1, dtype=torch.int32, device=dev)
+        step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        packed = unet.packed()
+
+        def run(n, graph=1):
+            L.check(vdx_p_sample_loop(h.ptr, L.ptr(unet.flat_params), L.ptr(packed), L.ptr(img), L.ptr(eps), L.ptr(t_dev), L.ptr(step_dev),
+                                      L.ptr(gd._ptab), T_STEPS, n, 0, 1000 + rank, 1, L.ptr(ws), ws.numel(), B, graph, L.stream_ptr()))
+        log(f'rank {rank}: dim {dim} {Fr}f x {S}x{S} ready (B={B}, mode={args.mode}); warm-up ...')
+        run(max(warmup, 2))                            # untimed: eager step + graph capture + replays
+        torch.cuda.synchronize(dev)
+        log('warm-up done; timing ...')
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        run(steps)                                     # timed: exactly K graph replays
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        if rank == 0 and roofline:
+            log('roofline leg: events around every kernel launch of 3 eager steps of the same loop ...')
+            rec = time_kernels_in_step(lambda n: run(n, 0), dev)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    assert torch.isfinite(img).all(), 'sampling produced non-finite values'
+    del img, eps, ws
+    unet._ws.clear()
+    torch.cuda.empty_cache()
+    return elapsed / steps * 1e3, act, rec
+
+
+def kernel_row(key, d, mode, ms_per_step):
+    """One (kernel, shape) entry of the roofline table: both fractions, and which roofline binds by arithmetic intensity."""
+    mfma_peak = MFMA_PEAK_TFLOPS[mode]
+    tflops = d['flops'] / (d['ms'] * 1e-3) / 1e12 if d['ms'] > 0 else 0.0
+    gbs = d['bytes'] / (d['ms'] * 1e-3) / 1e9 if d['ms'] > 0 else 0.0
+    ai = d['flops'] / d['bytes'] if d['bytes'] > 0 else 0.0
+    hbm_bound = ai < (mfma_peak * 1e12) / (HBM_PEAK_GBS * 1e9)
+    return {'kernel': key[0], 'shape': key[1], 'launches_per_step': d['launches'], 'avg_launch_us': d['ms'] / max(d['launches'], 1) * 1e3,
+            'ms_per_step': d['ms'], 'share_of_step': d['ms'] / ms_per_step, 'gflop_per_launch': d['flops'] / max(d['launches'], 1) / 1e9,
+            'algorithmic_mb_per_launch': d['bytes'] / max(d['launches'], 1) / 1e6, 'arithmetic_intensity_flop_per_byte': ai,
+            'bound': 'hbm' if hbm_bound else 'mfma', 'mfma_tflops': tflops, 'mfma_frac': tflops / mfma_peak, 'hbm_gbs': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS}
 
 
 def main():
@@ -313,56 +304,8 @@ def main():
         backend = f'{dist.get_backend()} (RCCL), world_size {dist.get_world_size()}'
         log(f'rank {rank}/{world} on cuda:{local}: process group up: {backend}')
 
-    from video_diffusion_nnx_amd import _lib as L
-    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion, vdx_p_sample_loop
-    from video_diffusion_nnx_amd.unet3d import Unet3D
-
     B, Fr, S = args.batch, args.frames, args.size
-    unet = Unet3D(dim=args.dim, rngs=0, channels=1, mode=args.mode, device=dev, attn_fp8=args.attn_fp8)
-    gd = GaussianDiffusion(unet, image_size=S, num_frames=Fr, channels=1, timesteps=T_STEPS, loss_type='l2')
-    h = unet.handle(Fr, S)
-    act = args.act_storage if args.act_storage != 'auto' else ('bf16' if args.mode == 'bf16' else 'f32')
-    unet.act_bf16 = (act == 'bf16')
-    unet.apply_activation_storage(h)
-    ws = unet.workspace(B, Fr, S)
-    stream = torch.cuda.Stream(device=dev)
-    with torch.cuda.stream(stream):
-        img = gd.randn((B, 1, Fr, S, S), 1000 + rank, 0)
-        eps = torch.empty(B, Fr, S, S, 1, device=dev)
-        t_dev = torch.full((B,), T_STEPS - 1, dtype=torch.int32, device=dev)
-        step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
-        packed = unet.packed()
-
-        def run(n):
-            L.check(vdx_p_sample_loop(h.ptr, L.ptr(unet.flat_params), L.ptr(packed), L.ptr(img), L.ptr(eps), L.ptr(t_dev), L.ptr(step_dev),
-                                      L.ptr(gd._ptab), T_STEPS, n, 0, 1000 + rank, 1, L.ptr(ws), ws.numel(), B, 1, L.stream_ptr()))
-        log(f'rank {rank}: model ready (B={B}, mode={args.mode}); warm-up ...')
-        run(max(args.warmup, 2))                       # untimed: eager step + graph capture + replays
-        torch.cuda.synchronize(dev)
-        log('warm-up done; timing ...')
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        run(args.steps)                                # timed: exactly K graph replays
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        elapsed = time.perf_counter() - t0
-        per = None
-        if rank == 0 and not args.no_roofline:
-            def run_eager(n):
-                L.check(vdx_p_sample_loop(h.ptr, L.ptr(unet.flat_params), L.ptr(packed), L.ptr(img), L.ptr(eps), L.ptr(t_dev), L.ptr(step_dev),
-                                          L.ptr(gd._ptab), T_STEPS, n, 0, 1000 + rank, 1, L.ptr(ws), ws.numel(), B, 0, L.stream_ptr()))
-            log('roofline leg: events around every conv launch of 3 eager steps of the same loop ...')
-            per, ev_overhead_us = time_convs_in_step(run_eager, dev, args.mode)
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
-    assert torch.isfinite(img).all(), 'sampling produced non-finite values'
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step, act, rec = sampling_leg(args, dev, world, rank, args.dim, Fr, S, B, args.steps, args.warmup, not args.no_roofline)
     value = world * B * Fr / (T_STEPS * ms_per_step * 1e-3)
 
     line = {
@@ -376,46 +319,48 @@ def main():
                    'process_group': backend or 'none (single process)'},
     }
     log(f'timed region done: {ms_per_step:.3f} ms/step')
-    del img, eps, ws
-    unet._ws.clear()
-    torch.cuda.empty_cache()
+    if not args.no_y_shape:
+        # secondary: the YAML-literal config_v2_2 (configs/config_v2_2.yaml: dim 32, 10 frames, 64 x 64) -- what `sample.py --config
+        # configs/config_v2_2.yaml` runs; same loop, same batch, fewer steps
+        yms, _, _ = sampling_leg(args, dev, world, rank, 32, 10, 64, B, max(5, args.steps // 2), 3, False)
+        line['y_shape'] = {'workload': f'configs/config_v2_2.yaml as written: Unet3D dim=32 C=1, 10f x 64x64, T={T_STEPS}', 'batch_per_gpu': B,
+                           'ms_per_step': yms, 'frames_per_s': world * B * 10 / (T_STEPS * yms * 1e-3),
+                           'tflops': world * B * 54.09e9 / (yms * 1e-3) / 1e12, 'n_shape_tflops': world * B * 250.77e9 / (ms_per_step * 1e-3) / 1e12}
+        log(f"Y shape: {yms:.3f} ms/step, {line['y_shape']['frames_per_s']:.1f} frames/s")
     if not args.no_train:
         log('training leg (p_losses fwd+bwd + bucketed all-reduce + Adam/EMA) ...')
         line['train'] = train_leg(args, dev, world, rank)         # every rank takes part (collectives inside)
         log(f"training leg done: {line['train']['ms_per_step']:.2f} ms/step, {line['train']['samples_per_s']:.1f} samples/s")
-    if rank == 0 and not args.no_roofline:
-        sym, d = max(per.items(), key=lambda kv: kv[1]['ms'])
-        tflops = d['flops'] / (d['ms'] * 1e-3) / 1e12
-        gbs = d['bytes'] / (d['ms'] * 1e-3) / 1e9
-        mfma_peak = MFMA_PEAK_TFLOPS[args.mode]
-        # which roofline binds this kernel: arithmetic intensity against the machine balance (peak FLOP/s / peak B/s)
-        hbm_bound = (d['flops'] / d['bytes']) < (mfma_peak * 1e12) / (HBM_PEAK_GBS * 1e9)
-        traffic, traffic_source = None, None             # HBM bytes per launch from committed rocprofv3 PMC passes of THIS workload
+    if rank == 0 and rec is not None:
+        per, sequence, ev_overhead_us = rec
+        rows = sorted((kernel_row(k, d, args.mode, ms_per_step) for k, d in per.items()), key=lambda r: -r['ms_per_step'])
+        top = rows[0]                                     # the (kernel, shape) with the largest time share of the step, over ALL kernels
+        traffic, traffic_source = None, None              # HBM bytes per launch from committed rocprofv3 PMC passes of THIS workload
         for tname in TRAFFIC_FILES:
             tpath = os.path.join(ROOT, 'profiles', tname)
             if not os.path.exists(tpath):
                 continue
             tj = json.load(open(tpath))
+            tk = f"{top['kernel']} | {top['shape']}"
             if (tj.get('batch') == B and tj.get('mode') == args.mode and tj.get('dim') == args.dim and tj.get('act', 'f32') == act
-                    and sym in tj.get('kernels', {})):
-                traffic = tj['kernels'][sym]['hbm_bytes_per_launch']
+                    and tk in tj.get('kernels', {})):
+                traffic = tj['kernels'][tk]['hbm_bytes_per_launch']
                 traffic_source = (f'profiles/{tname}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command (FETCH doubled per '
                                   'MI355X_MICROARCH.md), committed -- NOT collected in this run')
                 break
-        line['roofline'] = {'bound': 'hbm' if hbm_bound else 'mfma',
-                            'achieved': gbs if hbm_bound else tflops, 'peak': HBM_PEAK_GBS if hbm_bound else mfma_peak,
-                            'unit': 'GB/s' if hbm_bound else 'TFLOP/s', 'frac': (gbs / HBM_PEAK_GBS) if hbm_bound else (tflops / mfma_peak),
-                            'traffic': traffic, 'traffic_source': traffic_source,
-                            'kernel': sym, 'launches_per_step': d['launches'], 'avg_launch_ms': d['ms'] / d['launches'],
-                            'how': 'HIP events around every conv launch of 3 eager steps of the timed loop (library hook); '
-                                   f'empty event pair = {ev_overhead_us:.1f} us, subtracted',
-                            'avg_algorithmic_mb_per_launch': d['bytes'] / d['launches'] / 1e6,
-                            'avg_gflop_per_launch': d['flops'] / d['launches'] / 1e9,
-                            'arithmetic_intensity_flop_per_byte': d['flops'] / d['bytes'],
-                            'mfma_tflops': tflops, 'mfma_frac': tflops / mfma_peak, 'hbm_gbs': gbs, 'hbm_frac': gbs / HBM_PEAK_GBS,
-                            'share_of_step': d['ms'] / ms_per_step,
-                            'all_conv_symbols': {k: {'ms_per_step': v['ms'], 'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
-                                                     'gbs': v['bytes'] / (v['ms'] * 1e-3) / 1e9} for k, v in per.items()}}
+        hb = top['bound'] == 'hbm'
+        line['roofline'] = {'bound': top['bound'], 'achieved': top['hbm_gbs'] if hb else top['mfma_tflops'],
+                            'peak': HBM_PEAK_GBS if hb else MFMA_PEAK_TFLOPS[args.mode], 'unit': 'GB/s' if hb else 'TFLOP/s',
+                            'frac': top['hbm_frac'] if hb else top['mfma_frac'], 'traffic': traffic, 'traffic_source': traffic_source,
+                            'kernel': f"{top['kernel']} | {top['shape']}",
+                            'how': 'HIP events around EVERY kernel launch of 3 eager steps of the timed loop (library hook vdx_set_launch_hook), keyed by '
+                                   f'(kernel, template arguments + shape); empty event pair = {ev_overhead_us:.1f} us, subtracted; the row with the largest share of the step',
+                            **{k: top[k] for k in ('launches_per_step', 'avg_launch_us', 'gflop_per_launch', 'algorithmic_mb_per_launch',
+                                                   'arithmetic_intensity_flop_per_byte', 'mfma_tflops', 'mfma_frac', 'hbm_gbs', 'hbm_frac', 'share_of_step')},
+                            'bracketed_ms_per_step': sum(r['ms_per_step'] for r in rows),
+                            'all_kernels': [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
+        if args.launch_seq:
+            json.dump({'batch': B, 'mode': args.mode, 'dim': args.dim, 'act': act, 'sequence': sequence}, open(args.launch_seq, 'w'))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log('cpu_baseline leg (oracle on host cores) ...')
         line['cpu_baseline'] = cpu_baseline(args.dim, Fr, S)

@@ -89,18 +89,20 @@ typedef struct {
 int vdx_conv_forward(int mode, const vdx_conv_desc* d, void* stream);
 
 /* Instrumentation (bench.py's roofline leg): a process-global hook the library calls immediately before (phase 0) and after
- * (phase 1) EVERY convolution launch -- inside vdx_unet_forward / vdx_p_sample_loop too -- with the kernel it dispatched, so that
- * a caller can bracket each launch with its own events on `stream` while the real step runs.  NULL disables.  Not for use while
- * a stream is being captured into a graph (run the loop with use_graph = 0). */
+ * (phase 1) EVERY kernel launch of the forward / sampling path -- inside vdx_unet_forward / vdx_p_sample_loop too -- so that a caller
+ * can bracket each launch with its own events on `stream` while the real step runs.  `kernel` = the __global__ function's name
+ * without template arguments (a substring of the name rocprofv3 prints); `shape` = its template arguments + the operand shape as
+ * text (the key bench.py groups launches by: one symbol serves several levels of the network); flops / bytes = the ALGORITHMIC work
+ * of this launch (SURVEY 8d op-level definition: 2*M*N*K per contraction; input + output tensors in their storage type + weights).
+ * The strings are only valid during the call.  NULL disables.  Not for use while a stream is being captured into a graph (run the
+ * loop with use_graph = 0). */
 typedef struct {
-    int kernel;                   /* 0 conv_igemm_kernel, 1 conv64p_kernel, 2 conv128x64p_kernel, 3 conv3x3_ws_kernel, 4 conv4x4_ws_kernel, 5 conv1x1_pw_kernel<bc>, 6 conv64d_kernel */
-    int mode, bc, nw, inf;        /* conv_igemm template arguments <mode, BC, 2, NW, INF> */
-    int geo, pro;                 /* conv3x3_ws <GEO, PRO>; conv4x4_ws <GEO, 1 + kind, bc>; conv64p <IN16, PRO, OUT16> uses x_bf16 / pro / y_bf16 */
-    int x_bf16, y_bf16;
-    int cin, cout, h, w, nf, taps, kind, stride;     /* nf = batch * frames; kind 1 = ConvTranspose (4 phases, one launch) */
-} vdx_conv_launch_info;
-typedef void (*vdx_conv_launch_hook)(void* user, int phase, const vdx_conv_launch_info* info, void* stream);
-void vdx_set_conv_launch_hook(vdx_conv_launch_hook hook, void* user);
+    const char* kernel;
+    const char* shape;
+    double flops, bytes;
+} vdx_launch_info;
+typedef void (*vdx_launch_hook)(void* user, int phase, const vdx_launch_info* info, void* stream);
+void vdx_set_launch_hook(vdx_launch_hook hook, void* user);
 
 /* ResnetBlock tail: out = SiLU(GroupNorm(y2; stats, gn_gamma, gn_beta)) + LayerNorm_C(r; ln_gamma, ln_beta)
  * (reference: modules.py:173-179 for Block 2 and :240-243 `h + norm_2(res_conv(x))`).  r is res_conv(x), or x itself
@@ -287,6 +289,14 @@ int vdx_ddim_sample_loop(vdx_handle* h, const float* params, const void* packed,
                          uint64_t* step_dev, const float* alphas_cumprod, const int* seq, int seq_len, int nsteps, const float* cond,
                          int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream);
 
+/* vdx_ddim_sample_loop with use_dynamic_thres inside the captured step (the threshold of gaussian_diffusion.py:205-217 applied to DDIM's
+ * x0): tables = the [5][T] tables of vdx_p_sample_step (rows 0, 1 are read), thres_buf [B] floats scratch, percentile in (0, 1].
+ * percentile <= 0 is exactly vdx_ddim_sample_loop. */
+int vdx_ddim_sample_loop_dyn(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
+                             uint64_t* step_dev, const float* alphas_cumprod, const int* seq, int seq_len, int nsteps, const float* cond,
+                             int clip_denoised, const float* tables, int timesteps, float percentile, float* thres_buf, void* workspace,
+                             size_t workspace_bytes, int batch, int use_graph, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Backward building blocks (autodiff of the forward operators; reference trainer.py:361 jax.value_and_grad).
  * ---------------------------------------------------------------------------------------------- */
@@ -380,6 +390,25 @@ int vdx_loss_grad(const float* eps_hat, const float* noise, float* d_eps_hat, in
  * (1/world_size after a sum all-reduce).  If do_ema: ema = decay * ema + (1 - decay) * p_new. */
 int vdx_adam_ema_step(float* params, const float* grads, float* m, float* v, float* ema, long n, float lr, float b1, float b2,
                       float eps, long step_count, float grad_scale, int do_ema, float ema_decay, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data-parallel communicator (reference trainer.py:161-177, 307-320: the batch is sharded over a 'data' mesh axis and XLA inserts
+ * the all-reduce of every gradient behind jax.value_and_grad, trainer.py:361 -- SURVEY section 2, collective C1).  Here: one
+ * process per GPU, one RCCL communicator per handle, the flat gradient buffer reduced bucket by bucket as the staged backward
+ * finishes them.  RCCL is loaded at run time on the first call (no link-time dependency).
+ * ---------------------------------------------------------------------------------------------- */
+#define VDX_UNIQUE_ID_BYTES 128
+
+/* rank 0 creates the rendezvous id (ncclGetUniqueId) and hands its 128 bytes to the other ranks through any channel it has (a
+ * torch.distributed broadcast, a file, MPI); host memory. */
+int vdx_comm_unique_id(void* unique_id_out);
+/* joins the communicator of `world` ranks as `rank` on the CURRENT device (collective: every rank calls it). */
+int vdx_comm_init(vdx_handle* h, int rank, int world, const void* unique_id);
+/* in-place SUM all-reduce of count floats (a bucket of the flat gradient buffer) enqueued on `stream`; the mean's 1/world is folded
+ * into vdx_adam_ema_step's grad_scale. */
+int vdx_allreduce_bucket(vdx_handle* h, float* ptr, size_t count, void* stream);
+int vdx_comm_world(const vdx_handle* h);         /* ranks of the handle's communicator, 1 when none */
+int vdx_comm_destroy(vdx_handle* h);             /* also done by vdx_destroy */
 
 #ifdef __cplusplus
 }

@@ -166,7 +166,10 @@ class DiffusionRef:
             a_t = ac[t]
             a_n = ac[tn] if tn >= 0 else torch.ones((), dtype=ac.dtype)
             x0 = (x - (1 - a_t).sqrt() * eps) / a_t.sqrt()
-            if clip_denoised:
+            if clip_denoised and self.use_dynamic_thres:      # the threshold of p_mean_variance (gaussian_diffusion.py:205-220) applied to DDIM's x0
+                s = torch.quantile(x0.abs().reshape(b, -1), self.dynamic_thres_percentile, dim=-1).clamp_min(1.0).reshape(-1, 1, 1, 1, 1)
+                x0 = torch.maximum(torch.minimum(x0, s), -s) / s
+            elif clip_denoised:
                 x0 = x0.clamp(-1.0, 1.0)
             eps2 = (x - a_t.sqrt() * x0) / (1 - a_t).sqrt()
             x = a_n.sqrt() * x0 + (1 - a_n).sqrt() * eps2

@@ -5,6 +5,7 @@ Extensions: --mode {bf16,f16,f32}; --random-init (no checkpoint); --timesteps N 
 --attn-fp8 (bf16 mode: QK^T / PV of the <= 16-token attention blocks on fp8 MFMA operands)."""
 import argparse
 import logging
+import os
 import pathlib
 
 import yaml
@@ -46,6 +47,27 @@ def main(argv=None):
     if a.checkpoint_path is None and not a.random_init:
         ap.error('--checkpoint-path is required (or pass --random-init)')
 
+    # one process per GPU under `python -m torch.distributed.run --nproc-per-node N sample.py ...` (reference gaussian_diffusion.py:278-298
+    # shards the batch over the local devices): every rank draws batch_size / N of the videos and writes its own GIFs
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            local = int(os.environ.get('LOCAL_RANK', '0'))
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            torch.cuda.set_device(local)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    try:
+        _run(a, ap, rank, world)
+    finally:
+        if world > 1:
+            import torch.distributed as dist
+            if dist.is_initialized() and os.environ.get('VDX_KEEP_PROCESS_GROUP') != '1':
+                dist.destroy_process_group()
+
+
+def _run(a, ap, rank, world):
     from video_diffusion_nnx_amd.checkpoint import load_checkpoint
     from video_diffusion_nnx_amd.media import video_array_to_gif, videos_to_uint8
 
@@ -59,10 +81,18 @@ def main(argv=None):
         ckpt = pathlib.Path(a.checkpoint_path).resolve()
         gd, _ = load_checkpoint(gd, a.step, str(ckpt), load_ema_params=a.load_ema_params)
         logging.info('restored step %d from %s', a.step, ckpt)
-    videos = gd.sample(a.seed, batch_size=a.batch_size, ddim_steps=a.ddim_steps)
-    logging.info('drew %d videos', len(videos))
-    for i, frames in enumerate(videos_to_uint8(videos.cpu().numpy())):
-        target = out_dir / f'sample_{i}.gif'
+    videos = gd.sample(a.seed, batch_size=a.batch_size, ddim_steps=a.ddim_steps)          # this rank's shard of the global batch
+    logging.info('rank %d drew %d videos', rank, len(videos))
+    lo_hi = None
+    if world > 1:                                      # the uint8 scaling is batch-GLOBAL (reference sample.py:107-110): two scalars cross ranks
+        import torch
+        import torch.distributed as dist
+        mm = torch.stack([videos.min(), -videos.max()])
+        dist.all_reduce(mm, op=dist.ReduceOp.MIN)
+        lo_hi = (float(mm[0].item()), float(-mm[1].item()))
+    first = rank * len(videos)
+    for i, frames in enumerate(videos_to_uint8(videos.cpu().numpy(), lo_hi=lo_hi)):
+        target = out_dir / f'sample_{first + i}.gif'
         video_array_to_gif(frames, target)
         logging.info('wrote %s', target)
 

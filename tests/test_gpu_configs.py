@@ -306,29 +306,44 @@ def test_long_bottleneck_attention_96px(mode, tol):
         m.backward(torch.ones_like(y), torch.zeros_like(m.flat_params))
 
 
-def test_dim128_32f_128px_ddim_shape():
-    """The full configs[3] shape, B = 1: dim 128, C = 3, 32 frames of 128 x 128.  One bf16 forward (bf16 activation storage, as the
-    sampling loops run it) against the fp32 CPU oracle, then two DDIM steps through the captured loop (finite, deterministic)."""
-    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
-    from video_diffusion_nnx_amd.unet3d import Unet3D
+@pytest.fixture(scope='module')
+def configs3_reference():
+    """fp32 CPU oracle forward at the full configs[3] shape (one pass shared by the bf16 and the fp16 run)."""
     kw = dict(dim=128, channels=3)
     cfg = R.UnetConfig(**kw)
     p = R.random_params(cfg, seed=19, dtype=torch.float32)
-    m = Unet3D(rngs=0, mode='bf16', **kw)
-    m.load_state_dict(p)
     g = torch.Generator().manual_seed(10)
     x = torch.randn(1, 3, 32, 128, 128, generator=g)
     t = torch.tensor([500])
-    m.act_bf16 = True
+    with torch.no_grad():
+        ref = R.unet_forward(p, cfg, x, t).double()
+    return kw, p, x, t, ref
+
+
+@pytest.mark.parametrize('mode,tol', [('bf16', 3e-2), ('f16', 6e-3)])
+def test_dim128_32f_128px_ddim_shape(configs3_reference, mode, tol):
+    """The full configs[3] shape ("dim=128 Unet3D, 32-frame 128x128, DDIM-100 sampling fp16"), B = 1: dim 128, C = 3, 32 frames of
+    128 x 128.  One forward against the fp32 CPU oracle -- bf16 operands with bf16 activation storage (as the bf16 sampling loops run
+    it), and fp16 operands (VDX_MODE_F16, fp32 tensors: the configuration as BASELINE.json words it; fp32 oracle's own error vs fp64
+    is ~2e-6, fp16 operands measured ~1e-3) -- then two DDIM steps through the captured loop (finite, in [0, 1], deterministic)."""
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    kw, p, x, t, ref = configs3_reference
+    m = Unet3D(rngs=0, mode=mode, **kw)
+    m.load_state_dict(p)
+    m.act_bf16 = mode == 'bf16'
     y = m(x, t).cpu().double()
     m.act_bf16 = False
-    ref = R.unet_forward(p, cfg, x, t).double()
     r = _rel(y, ref)
-    print(f'dim128 32f x 128 x 128 bf16 storage: rel-L2 {r:.3e}')
-    assert r < 3e-2, r
+    print(f'dim128 32f x 128 x 128 {mode}: rel-L2 {r:.3e}')
+    assert r < tol, r
     gd = GaussianDiffusion(m, image_size=128, num_frames=32, channels=3, timesteps=1000)
     a = gd.ddim_sample_loop((1, 3, 32, 128, 128), 3, steps=2)
     assert a.shape == (1, 3, 32, 128, 128) and torch.isfinite(a).all() and 0.0 <= a.min().item() and a.max().item() <= 1.0
+    b = gd.ddim_sample_loop((1, 3, 32, 128, 128), 3, steps=2)
+    assert torch.equal(a, b)
+    del m, gd
+    torch.cuda.empty_cache()
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -410,3 +425,89 @@ def test_f16_ddim_chain():
     err = ((out.cpu().double() - exp).norm() / exp.norm()).item()
     print(f'f16 DDIM-{S} chain rel-L2 {err:.3e}')
     assert err < 2e-2, err
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (g) the YAML-literal config_v2_2 (configs/config_v2_2.yaml: dim 32, 10 frames, 64 x 64) -- what `sample.py --config
+#     configs/config_v2_2.yaml` runs and the reference's only published result (README.md:33-54)
+# ------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize('mode,storage,tol', [('f32', 'f32', 5e-5), ('bf16', 'f32', 2e-2), ('bf16', 'bf16', 3e-2)])
+def test_config_v2_2_yaml_shape_forward(mode, storage, tol):
+    """Y shape: level 0 at C = 32 (off the 64-channel persistent kernels), 10-frame sequences (padded 16-token attention tiles)."""
+    import pathlib, yaml
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    cfg_y = yaml.safe_load((pathlib.Path(__file__).resolve().parents[1] / 'configs' / 'config_v2_2.yaml').read_text())
+    u, d = cfg_y['unet'], cfg_y['diffusion']
+    assert (u['dim'], u['channels'], d['num_frames'], d['image_size'], d['timesteps']) == (32, 1, 10, 64, 1000)
+    kw = dict(dim=u['dim'], channels=u['channels'], dim_mults=tuple(u['dim_mults']))
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=31, dtype=torch.float64)
+    m = Unet3D(rngs=0, mode=mode, **kw)
+    m.load_state_dict({k: v.float() for k, v in p.items()})
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(2, 1, d['num_frames'], d['image_size'], d['image_size'], generator=g)
+    t = torch.tensor([7, 640])
+    m.act_bf16 = storage == 'bf16'
+    y = m(x, t).cpu().double()
+    m.act_bf16 = False
+    ref = R.unet_forward(p, cfg, x.double(), t)
+    r = _rel(y, ref)
+    print(f'Y shape (dim 32, 10f x 64 x 64) {mode} operands / {storage} storage: rel-L2 {r:.3e}')
+    assert r < tol, r
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (h) the full T = 1000 p_sample_loop at the N shape (BASELINE.json configs[1]; reference gaussian_diffusion.py:264-320)
+# ------------------------------------------------------------------------------------------------------------------
+
+def test_full_1000_step_sample_north_star_shape():
+    """GaussianDiffusion.sample for ALL 1000 steps at dim 64 / 16f x 64 x 64, B = 2, bf16 operands + bf16 activation storage (the
+    benchmarked configuration).  No oracle can follow a 1000-step chain at this size, so the checks are the chain's own invariants:
+    the first 3 graph-replayed steps equal 3 eager steps bitwise; t walks T-1 ... 0 (499 after 500 steps) and the device draw counter
+    ends at exactly T; the result is finite and in [0, 1] (clip_denoised + unnormalize_img); two runs with one seed are bit-equal;
+    another seed gives another video."""
+    from video_diffusion_nnx_amd import _lib as L
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion, vdx_p_sample_loop
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+    T, B, Fr, S = 1000, 2, 16, 64
+    unet = Unet3D(rngs=0, mode='bf16', **N_KW)
+    gd = GaussianDiffusion(unet, image_size=S, num_frames=Fr, channels=1, timesteps=T)
+    dev = unet.device
+    h = unet.handle(Fr, S)
+    unet.act_bf16 = True
+    unet.apply_activation_storage(h)
+    ws = unet.workspace(B, Fr, S)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        x_T = gd.randn((B, 1, Fr, S, S), 77, 0)
+        eps = torch.empty(B, Fr, S, S, 1, device=dev)
+
+        def chain(n_list, graph):
+            img = x_T.clone()
+            t_dev = torch.full((B,), T - 1, dtype=torch.int32, device=dev)
+            step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+            states = []
+            for n in n_list:
+                L.check(vdx_p_sample_loop(h.ptr, L.ptr(unet.flat_params), L.ptr(unet.packed()), L.ptr(img), L.ptr(eps), L.ptr(t_dev), L.ptr(step_dev),
+                                          L.ptr(gd._ptab), T, n, 0, 77, 1, L.ptr(ws), ws.numel(), B, graph, L.stream_ptr()))
+                st.synchronize()
+                states.append((img.clone(), t_dev.clone().cpu(), int(step_dev.item())))
+            return states
+        eager = chain([3], 0)
+        graph = chain([3, 497, 500], 1)
+    unet.act_bf16 = False
+    assert torch.equal(eager[0][0], graph[0][0]), 'graph replay != eager loop after 3 steps'
+    assert graph[0][2] == 3 and graph[0][1].tolist() == [T - 4] * B
+    assert graph[1][2] == 500 and graph[1][1].tolist() == [T - 501] * B
+    assert graph[2][2] == T and graph[2][1].tolist() == [0] * B
+    x0 = graph[2][0]
+    assert torch.isfinite(x0).all() and x0.abs().max().item() <= 1.0
+    a = gd.sample(77, batch_size=B)
+    assert a.shape == (B, 1, Fr, S, S) and torch.isfinite(a).all() and 0.0 <= a.min().item() and a.max().item() <= 1.0
+    assert torch.allclose(a, (x0 + 1) * 0.5, rtol=0, atol=1e-6), 'GaussianDiffusion.sample != the piecewise-driven loop with the same seed'
+    b = gd.sample(77, batch_size=B)
+    assert torch.equal(a, b), 'same seed, different video'
+    c = gd.sample(78, batch_size=B)
+    assert not torch.equal(a, c)
+    assert a.std().item() > 1e-3                       # not a constant image

@@ -240,3 +240,11 @@ def test_dynamic_threshold_quantile_and_graph_loop():
                              [torch.from_numpy(philox_ref.randn(n, 5, 1 + k)).double().reshape(shape) for k in range(T)])
     err = (out.cpu().double() - exp).abs().max().item()
     assert err < 1e-3, err
+    # the DDIM loop honours the flag too (extension; round 2 sampled with the static clip under ddim_steps): threshold inside the captured step
+    S = 6
+    out_d = gd.ddim_sample_loop(shape, 5, steps=S)
+    exp_d = (refd.ddim_sample_loop(torch.from_numpy(philox_ref.randn(n, 5, 0)).double().reshape(shape), S) + 1) * 0.5
+    err_d = (out_d.cpu().double() - exp_d).abs().max().item()
+    assert err_d < 1e-3, err_d
+    static = GaussianDiffusion(unet, image_size=8, num_frames=5, channels=3, timesteps=T).ddim_sample_loop(shape, 5, steps=S)
+    assert (static - out_d).abs().max().item() > 1e-4           # the threshold is really applied (x_T ~ N(0,1): |x0_hat| quantiles exceed 1)

@@ -172,3 +172,105 @@ def test_two_rank_train_steps_match_one_rank_on_global_batch():
 def _orig(ukw):
     m = _setup(ukw, 4, 8, 'f32')
     return m.flat_params.cpu().numpy()
+
+
+# ---- sampling shards by sample (reference gaussian_diffusion.py:278-298: batch split over the devices, no collective in a step) ----
+
+def _sample_rank(rank, world, port, out_dir, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0')
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+        m = _setup(dict(dim=16, channels=1, dim_mults=(1, 2)), 4, 8, 'bf16')
+        gd = GaussianDiffusion(m, image_size=8, num_frames=4, channels=1, timesteps=6)
+        v = gd.sample(21, batch_size=4)                                    # GLOBAL batch 4 -> this rank's 2
+        import sample                                                      # the CLI under the same group: rank r writes sample_{2r}, sample_{2r+1}
+        cfg = {'unet': dict(dim=16, dim_mults=[1, 2], channels=1, rngs_seed=0, use_bert_text_cond=False),
+               'diffusion': dict(image_size=8, num_frames=4, channels=1, timesteps=6, loss_type='l2'), 'trainer': {}}
+        import yaml
+        cfg_path = os.path.join(out_dir, f'cfg{rank}.yaml')
+        open(cfg_path, 'w').write(yaml.safe_dump(cfg))
+        os.environ['VDX_KEEP_PROCESS_GROUP'] = '1'
+        sample.main(['--config', cfg_path, '--random-init', '--batch-size', '4', '--seed', '21', '--output-path', os.path.join(out_dir, 'gifs')])
+        q.put((rank, v.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sampling_shards_the_batch(tmp_path):
+    """GaussianDiffusion.sample / sample.py inside a 2-rank group (two processes on one GPU, gloo): each rank draws HALF of the
+    global batch from its own Philox stream shard_key(key, rank) -- distinct videos, their union = what one process draws with the
+    two shard keys -- and writes its own GIF indices."""
+    import torch.multiprocessing as mp
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion, shard_key
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    ps = [ctx.Process(target=_sample_rank, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = dict(q.get(timeout=300) for _ in ps)
+    for p in ps:
+        p.join(60)
+    assert outs[0].shape == outs[1].shape == (2, 1, 4, 8, 8)
+    assert not np.array_equal(outs[0], outs[1]), 'both ranks drew the same videos'
+    m = _setup(dict(dim=16, channels=1, dim_mults=(1, 2)), 4, 8, 'bf16')
+    gd = GaussianDiffusion(m, image_size=8, num_frames=4, channels=1, timesteps=6)
+    for r in range(2):
+        one = gd.sample(shard_key(21, r, 2), batch_size=2).cpu().numpy()
+        assert np.array_equal(one, outs[r]), f'rank {r} shard != the 1-rank draw with its shard key'
+    gifs = sorted(p.name for p in (tmp_path / 'gifs').glob('sample_*.gif'))
+    assert gifs == ['sample_0.gif', 'sample_1.gif', 'sample_2.gif', 'sample_3.gif'], gifs
+
+
+# ---- the communicator behind the C ABI (SURVEY 8b: vdx_comm_init / vdx_allreduce_bucket; RCCL inside libvdx.so) ----
+
+def test_abi_communicator_one_rank_train_step():
+    """One GPU = a 1-rank RCCL communicator: a train step whose buckets go through vdx_allreduce_bucket on the reducer's side stream
+    must leave exactly the parameters of the torch.distributed-free step (sum over one rank = identity), the handle reports its world,
+    a second vdx_comm_init on the same handle fails loudly.  N > 1 ranks over xGMI: unmeasured on hardware (no multi-GPU box here)."""
+    import ctypes as C
+    import tempfile
+    from video_diffusion_nnx_amd import _lib as L
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+    from video_diffusion_nnx_amd.trainer import Trainer
+    from video_diffusion_nnx_amd.unet3d import vdx_allreduce_bucket, vdx_comm_init, vdx_comm_unique_id, vdx_comm_world
+    ukw, frames, size = dict(dim=16, channels=1, dim_mults=(1, 2)), 4, 8
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 1, frames, size, size, generator=g)
+    t = torch.randint(0, 100, (2,), generator=g)
+    noise = torch.randn(2, 1, frames, size, size, generator=g)
+    res = {}
+    keep = Trainer.comm_backend, Trainer.min_bucket_floats
+    try:
+        Trainer.min_bucket_floats = 1 << 12
+        for backend in ('torch', 'abi'):
+            Trainer.comm_backend = backend
+            m = _setup(ukw, frames, size, 'f32')
+            gd = GaussianDiffusion(m, image_size=size, num_frames=frames, channels=1, timesteps=100, loss_type='l2')
+            tmp = tempfile.mkdtemp()
+            tr = Trainer(gd, tmp, dataset_path='synthetic:8', train_batch_size=2, train_num_steps=2, train_lr=1e-3, results_folder=tmp)
+            assert len(tr.buckets) >= 2
+            for s in range(2):
+                loss = tr.train_step(x, s, t=t, noise=noise)
+            torch.cuda.synchronize()
+            res[backend] = (m.flat_params.clone(), float(loss.item()))
+            if backend == 'abi':
+                h = m.handle(frames, size)
+                assert vdx_comm_world(h.ptr) == 1
+                buf = C.create_string_buffer(128)
+                L.check(vdx_comm_unique_id(buf))
+                assert vdx_comm_init(h.ptr, 0, 1, buf.raw) != 0 and b'already' in L.vdx_last_error()
+                v = torch.arange(1000, dtype=torch.float32, device=m.device)
+                L.check(vdx_allreduce_bucket(h.ptr, L.ptr(v), v.numel(), L.stream_ptr()))
+                torch.cuda.synchronize()
+                assert torch.equal(v.cpu(), torch.arange(1000, dtype=torch.float32))
+            else:
+                h = m.handle(frames, size)
+                assert vdx_allreduce_bucket(h.ptr, L.ptr(m.flat_params), 16, L.stream_ptr()) != 0       # no communicator: loud, not silent
+    finally:
+        Trainer.comm_backend, Trainer.min_bucket_floats = keep
+    assert torch.equal(res['torch'][0], res['abi'][0]) and res['torch'][1] == res['abi'][1]

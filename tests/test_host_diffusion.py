@@ -53,3 +53,13 @@ def test_helpers():
 def test_shape_check_and_loss_type(gd):
     with pytest.raises(AssertionError):
         gd(torch.zeros(2, 3, 2, 8, 9), 0)
+
+
+def test_shard_key_and_rank_world_outside_a_group():
+    """Data-parallel sampling (reference gaussian_diffusion.py:278-298): rank r's Philox seed depends on (key, r) only; one rank keeps the key."""
+    from video_diffusion_nnx_amd.gaussian_diffusion import dist_rank_world, shard_key, split_key
+    assert dist_rank_world() == (0, 1)
+    assert shard_key(5, 0, 1) == 5
+    ks = [shard_key(5, r, 4) for r in range(4)]
+    assert len(set(ks)) == 4 and ks[:2] == [shard_key(5, r, 2) for r in range(2)]
+    assert ks[2] == split_key(5, 3)[-1]

@@ -662,6 +662,19 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     }
 }
 
+// instrumentation (vdx.h: vdx_set_launch_hook): algorithmic work of an attention block over rows = nseq * L tokens: q|k|v
+// projection 2 C 3HD + core 4 L HD (+ out-projection 2 HD C when `with_out`) FLOP per token; x in + result out in their storage type + weights
+namespace {
+struct AttnWork { double flops, bytes; };
+AttnWork attn_work(const AttnArgs& a, int es_w, bool with_out) {
+    const double rows = (double)a.nseq * a.L, HD = a.heads * 32.0, eio = a.io_bf16 ? 2.0 : 4.0;
+    AttnWork w;
+    w.flops = rows * (2.0 * a.C * 3 * HD + 4.0 * a.L * HD + (with_out ? 2.0 * HD * a.C : 0.0));
+    w.bytes = rows * a.C * eio + (with_out ? rows * a.C * eio : rows * HD * 2.0) + es_w * (3.0 * HD * a.C + (with_out ? HD * a.C : 0.0));
+    return w;
+}
+}  // namespace
+
 template <int MODE, int NKT, int TMO, int TNO, bool IO16, bool F8 = false, bool FULL = false>
 static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
     using M = Mma<MODE>;
@@ -678,6 +691,8 @@ static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
     const int nsub_cap = 32;
     const int nsub = (int)std::min<long>(nsub_cap, std::max<long>(1, subtiles / 1024));
     const long blocks = (subtiles + nsub - 1) / nsub;
+    const AttnWork aw = attn_work(a, M::ES, true);
+    LaunchScope ls(st, "attention_h8_kernel", aw.flops, aw.bytes, "<%d, %d, %d, %d, %d, %d, %d> C%d L%d nseq%ld", MODE, NKT, TMO, TNO, (int)IO16, (int)F8, (int)FULL, a.C, a.L, a.nseq);
     hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, st, a, nsub);
     return hipGetLastError();
 }
@@ -831,6 +846,8 @@ hipError_t launch_attention_heads(AttnArgs a, hipStream_t st) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
+        const AttnWork aw = attn_work(a, 2, false);
+        LaunchScope ls(st, "attention_head_kernel", aw.flops, aw.bytes, "<io16 %d, %d, fp8 %d> C%d L%d nseq%ld", a.io_bf16, TT, a.fp8_core, a.C, a.L, a.nseq);
         hipLaunchKernelGGL(kfn, dim3((unsigned)((chunks + 7) / 8 * 64)), dim3(512), lds, st, a, (int)spb, (int)chunks);
         return hipGetLastError();
     };
@@ -842,6 +859,8 @@ template <int MODE, int TMA>
 static hipError_t launch_attn_reg_t(const AttnArgs& a, hipStream_t st) {
     const size_t lds = 512 + (size_t)(64 + 96) * ROW_STRIDE + (size_t)TMA * 16 * (32 * Mma<MODE>::ES + 16);
     const long blocks = (a.nseq + 3) / 4;
+    const AttnWork aw = attn_work(a, Mma<MODE>::ES, true);
+    LaunchScope ls(st, "attention_reg_kernel", aw.flops, aw.bytes, "<%d, %d, fp8 %d> C%d L%d nseq%ld io16 %d", MODE, TMA, a.fp8_core, a.C, a.L, a.nseq, a.io_bf16);
     if constexpr (MODE == MODE_BF16) {
         if (a.fp8_core) { hipLaunchKernelGGL((attention_reg_kernel<MODE, TMA, true>), dim3((unsigned)blocks), dim3(256), lds, st, a); return hipGetLastError(); }
     }
@@ -872,6 +891,8 @@ static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     const long blocks = (a.nseq + NSEQ - 1) / NSEQ;
+    const AttnWork aw = attn_work(a, Mma<MODE>::ES, true);
+    LaunchScope ls(st, "attention_kernel", aw.flops, aw.bytes, "<%d, %d, %d> C%d L%d nseq%ld io16 %d", MODE, LP, TMO, a.C, a.L, a.nseq, a.io_bf16);
     hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(256), lds, st, a);
     return hipGetLastError();
 }
@@ -971,6 +992,7 @@ hipError_t launch_attention_long_core(const float* qkv, float* o, long nseq, int
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    LaunchScope ls(st, "attention_long_core_kernel", 4.0 * nseq * L * L * heads * 32, 4.0 * nseq * L * heads * 32 * 4, "L%d nseq%ld heads%d", L, nseq, heads);
     hipLaunchKernelGGL(kfn, dim3((unsigned)nseq, heads), dim3(256), lds, st, qkv, o, L, heads, scale);
     return hipGetLastError();
 }

@@ -1187,22 +1187,23 @@ hipError_t launch_pack_weights_t(int mode, const float* src, void* dst, int taps
     return hipGetLastError();
 }
 
-// instrumentation hook (vdx.h: vdx_set_conv_launch_hook)
-static vdx_conv_launch_hook g_conv_hook = nullptr;
-static void* g_conv_hook_user = nullptr;
-void set_conv_launch_hook(vdx_conv_launch_hook hook, void* user) { g_conv_hook = hook; g_conv_hook_user = user; }
+// instrumentation (vdx.h: vdx_set_launch_hook): algorithmic work of one conv launch -- 2 * pixels_out * Cin * Cout * taps FLOP (ConvTranspose:
+// 4 effective taps per output pixel) and input + output (+ residual) tensors in their storage type + the packed weights
 namespace {
-struct HookScope {
-    vdx_conv_launch_info info; hipStream_t st;
-    HookScope(int mode, const ConvArgs& a, hipStream_t s, int kernel, int bc = 0, int nw = 0, int inf = 0, int geo = 0) : st(s) {
-        memset(&info, 0, sizeof(info));
-        info.kernel = kernel; info.mode = mode; info.bc = bc; info.nw = nw; info.inf = inf; info.geo = geo; info.pro = a.pro;
-        info.x_bf16 = a.x0_bf16; info.y_bf16 = a.y_bf16; info.cin = a.C0 + a.C1; info.cout = a.Cout; info.h = a.H; info.w = a.W; info.nf = a.NF;
-        info.taps = a.kind ? 16 : a.kh * a.kw; info.kind = a.kind; info.stride = a.stride;
-        if (g_conv_hook) g_conv_hook(g_conv_hook_user, 0, &info, st);
-    }
-    ~HookScope() { if (g_conv_hook) g_conv_hook(g_conv_hook_user, 1, &info, st); }
-};
+struct ConvWork { double flops, bytes; char shape[128]; };
+ConvWork conv_work(int mode, const ConvArgs& a) {
+    ConvWork w;
+    const double es = mode == MODE_F32 ? 4.0 : 2.0;
+    const int taps = a.kind ? 16 : a.kh * a.kw;
+    const double ho = a.kind ? 2.0 * a.H : (a.H + a.stride - 1) / a.stride, wo = a.kind ? 2.0 * a.W : (a.W + a.stride - 1) / a.stride;
+    const double cin = a.C0 + a.C1;
+    w.flops = 2.0 * a.NF * ho * wo * cin * a.Cout * (a.kind ? 4 : taps);
+    w.bytes = (double)a.NF * a.H * a.W * (a.C0 * (a.x0_bf16 ? 2.0 : 4.0) + a.C1 * (a.x1_bf16 ? 2.0 : 4.0)) + a.NF * ho * wo * a.Cout * (a.y_bf16 ? 2.0 : 4.0)
+            + (a.res ? a.NF * ho * wo * a.Cout * (a.res_bf16 ? 2.0 : 4.0) : 0.0) + es * taps * cin * a.Cout;
+    snprintf(w.shape, sizeof(w.shape), "%s%dx%d %d->%d %dx%dx%d%s%s%s%s", a.kind ? "convT" : "conv", a.kind ? 4 : a.kh, a.kind ? 4 : a.kw, a.C0 + a.C1, a.Cout,
+             a.NF, a.H, a.W, a.stride == 2 ? " s2" : "", a.pro ? " +prologue" : "", a.res ? " +res" : "", a.C1 ? " concat" : "");
+    return w;
+}
 }  // namespace
 
 hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
@@ -1218,15 +1219,18 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     if (b0 >= 0xFFFFFFF0ull || b1 >= 0xFFFFFFF0ull || bw >= 0xFFFFFFF0ull) return hipErrorInvalidValue;   // 32-bit buffer offsets
     a.x0_bytes = (unsigned)b0; a.x1_bytes = (unsigned)b1; a.w_bytes = (unsigned)bw;
     if (conv3x3_ws_eligible(mode, a)) {                                      // wide levels: persistent weight-streaming kernel
-        HookScope hs(mode, a, st, 3, 0, 0, 0, conv3x3_ws_geo(a));
+        const ConvWork cw = conv_work(mode, a);
+        LaunchScope ls(st, "conv3x3_ws_kernel", cw.flops, cw.bytes, "<%d, %s> %s", conv3x3_ws_geo(a), a.pro ? "true" : "false", cw.shape);
         return launch_conv3x3_ws(a, st);
     }
     if (conv4x4_ws_eligible(mode, a)) {                                      // 4x4 resampling convs of the wide levels
-        HookScope hs(mode, a, st, 4, a.Cout == 64 ? 64 : 128, 0, 0, a.kind == 1 ? a.H : a.H / 2);
+        const ConvWork cw = conv_work(mode, a);
+        LaunchScope ls(st, "conv4x4_ws_kernel", cw.flops, cw.bytes, "<%d, %d, %d> %s", a.kind == 1 ? a.H : a.H / 2, a.kind == 1 ? 2 : 1, a.Cout == 64 ? 64 : 128, cw.shape);
         return launch_conv4x4_ws(a, st);
     }
     if (conv1x1_pw_eligible(mode, a)) {                                      // 1x1 convs of the wide levels (bf16 tensors)
-        HookScope hs(mode, a, st, 5, conv1x1_pw_rows(a));
+        const ConvWork cw = conv_work(mode, a);
+        LaunchScope ls(st, "conv1x1_pw_kernel", cw.flops, cw.bytes, "<%d> %s", conv1x1_pw_rows(a), cw.shape);
         return launch_conv1x1_pw(a, st);
     }
     {   // persistent specialisation for the level-0 shape (see conv64p_kernel)
@@ -1236,14 +1240,16 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
             a.wrows >= 64 && a.wrow0 >= 0 && a.wrow0 + 64 <= a.wrows && (!a.res || (!a.pro && a.x0_bf16 && !a.res_bf16)) && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
             (!a.out_stats || (a.out_groups <= 32 && 64 % a.out_groups == 0))) {
             const bool dma_form = a.x0_bf16 && !a.pro;               // bf16 input, no prologue: input staged by LDS-DMA (conv64d_kernel)
-            HookScope hs(mode, a, st, dma_form ? 6 : 1);
+            const ConvWork cw = conv_work(mode, a);
+            LaunchScope ls(st, dma_form ? "conv64d_kernel" : "conv64p_kernel", cw.flops, cw.bytes, "<x16 %d, pro %d, y16 %d, res %d> %s", a.x0_bf16, a.pro, a.y_bf16, a.res ? 1 : 0, cw.shape);
             return dma_form ? launch_conv64d(a, st) : launch_conv64p(a, st);
         }
         const bool in16c = a.x0_bf16 && (!a.C1 || a.x1_bf16);
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.Cout == 64 && in16c && !a.pro &&
             ((a.C0 == 64 && a.C1 == 64) || (a.C0 == 128 && a.C1 == 0)) && a.wrows == 64 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 &&
             tiles >= 1024 && (!a.out_stats || (a.out_groups <= 32 && 32 % (64 / a.out_groups) == 0 && 64 % a.out_groups == 0))) {
-            HookScope hs(mode, a, st, 2);
+            const ConvWork cw = conv_work(mode, a);
+            LaunchScope ls(st, "conv128x64p_kernel", cw.flops, cw.bytes, "%s", cw.shape);
             return launch_conv128x64p(a, st);
         }
     }
@@ -1266,7 +1272,8 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
     dim3 grid((a.NF / a.NP) * a.tiles_y * a.tiles_x, (a.Cout + BC - 1) / BC, a.kind ? 4 : 1);
     const bool in16 = mode == MODE_BF16 && a.x0_bf16 && (!a.C1 || a.x1_bf16) && (a.C0 % 8 == 0) && (a.C1 % 8 == 0);
     const int inf = in16 ? 2 : (!a.x0_bf16 && !(a.C1 && a.x1_bf16)) ? 0 : (mode == MODE_BF16 && a.x0_bf16 && !a.C1) ? 1 : 3;
-    HookScope hs(mode, a, st, 0, BC, (BC == 128 || TN == 4) ? 8 : 4, (mode == MODE_BF16 || inf == 0) ? inf : 3);
+    const ConvWork cw = conv_work(mode, a);
+    LaunchScope ls(st, "conv_igemm_kernel", cw.flops, cw.bytes, "<%d, %d, 2, %d, %d> %s", mode, BC, (BC == 128 || TN == 4) ? 8 : 4, (mode == MODE_BF16 || inf == 0) ? inf : 3, cw.shape);
 #define VDX_LAUNCH_CONV_K(KFN_, NTH_)                                                                    \
     do {                                                                                                  \
         auto kfn = KFN_;                                                                                  \

@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void p_sample_kernel(PSampleArgs P) {
 //   x0 = (x - sqrt(1 - ac_t) eps) / sqrt(ac_t)        [clip to +-s, / s as p_sample does]
 //   eps' = (x - sqrt(ac_t) x0) / sqrt(1 - ac_t)       (re-derived from the CLIPPED x0, as the usual implementations do)
 //   out = sqrt(ac_next) x0 + sqrt(1 - ac_next) eps'
-__global__ __launch_bounds__(256) void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, float* __restrict__ out,
+// (x and out may alias -- vdx.h -- so neither is __restrict__)
+__global__ __launch_bounds__(256) void ddim_step_kernel(const float* x, const float* __restrict__ eps, float* out,
                                                         const float* __restrict__ ac, const int* __restrict__ seq,
                                                         const unsigned long long* __restrict__ step_dev, const float* __restrict__ thres,
                                                         int clip, int C, long per_sample) {
@@ -249,28 +250,33 @@ hipError_t launch_q_sample(const float* x0, const int* t, const float* noise, fl
 }
 
 hipError_t launch_p_sample(const PSampleArgs& a, int B, hipStream_t st) {
+    LaunchScope ls(st, "p_sample_kernel", 0.0, 12.0 * B * a.per_sample, "B%d px%ld", B, a.per_sample);
     hipLaunchKernelGGL(p_sample_kernel, dim3(ew_blocks((a.per_sample + 3) / 4), B), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
 hipError_t launch_advance(int* t, int B, unsigned long long* dev_offset, hipStream_t st) {
+    LaunchScope ls(st, "advance_kernel", 0.0, 0.0, "B%d", B);
     hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1024), 0, st, t, B, dev_offset);
     return hipGetLastError();
 }
 
 hipError_t launch_ddim_step(const float* x, const float* eps, float* out, const float* ac, const int* seq, const unsigned long long* step_dev,
                             const float* thres, int clip, int B, int C, long per_sample, hipStream_t st) {
+    LaunchScope ls(st, "ddim_step_kernel", 0.0, 12.0 * B * per_sample, "B%d px%ld", B, per_sample);
     hipLaunchKernelGGL(ddim_step_kernel, dim3(ew_blocks(per_sample), B), dim3(256), 0, st, x, eps, out, ac, seq, step_dev, thres, clip, C, per_sample);
     return hipGetLastError();
 }
 
 hipError_t launch_ddim_advance(int* t, int B, const int* seq, unsigned long long* step_dev, hipStream_t st) {
+    LaunchScope ls(st, "ddim_advance_kernel", 0.0, 0.0, "B%d", B);
     hipLaunchKernelGGL(ddim_advance_kernel, dim3(1), dim3(256), 0, st, t, B, seq, step_dev);
     return hipGetLastError();
 }
 
 hipError_t launch_dyn_thres(const float* x, const float* eps, const int* t, const float* tables, int T, float q, float* out, int B, int C,
                             long per_sample, hipStream_t st) {
+    LaunchScope ls(st, "dyn_thres_kernel", 0.0, 8.0 * B * per_sample, "B%d px%ld", B, per_sample);
     hipLaunchKernelGGL(dyn_thres_kernel, dim3(B), dim3(1024), 0, st, x, eps, t, tables, T, q, out, C, per_sample);
     return hipGetLastError();
 }

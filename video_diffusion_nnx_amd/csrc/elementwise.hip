@@ -285,6 +285,9 @@ static hipError_t launch_tail_rc16(const TailArgs& a, hipStream_t st) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
+        const double px = (double)a.batch * a.pix_per_sample;       // y2, x (concat) in + out, bf16; the 1x1 res_conv on the MFMA
+        LaunchScope ls(st, "resblock_tail_rc16_kernel", 2.0 * px * CIN * COUT, px * (CIN + 2.0 * COUT) * 2 + 2.0 * CIN * COUT, "<%d, %d, %s> px%ld x %d", CIN, COUT,
+                       a.C1 ? "true" : "false", a.pix_per_sample, a.batch);
         hipLaunchKernelGGL(kfn, dim3((unsigned)gx, a.batch), dim3(256), lds, st, a);
         return hipGetLastError();
     };
@@ -317,6 +320,8 @@ hipError_t launch_resblock_tail(TailArgs a, hipStream_t st) {
         const long total = tail_wgs > 0 ? tail_wgs : std::max<long>(2048, need * a.batch / 8);
         const int gx = (int)std::min<long>(need, std::max<long>(1, std::min<long>(2048, total / std::max(1, a.batch))));
         dim3 grid(gx, a.batch);
+        const double el = (double)a.batch * a.pix_per_sample * a.C;
+        LaunchScope ls(st, "resblock_tail16_kernel", 10.0 * el, 3.0 * el * 2, "<%d> C%d px%ld x %d", vpl, a.C, a.pix_per_sample, a.batch);
         switch (vpl) {
             case 1: hipLaunchKernelGGL(resblock_tail16_kernel<1>, grid, dim3(256), 0, st, a); break;
             case 2: hipLaunchKernelGGL(resblock_tail16_kernel<2>, grid, dim3(256), 0, st, a); break;
@@ -335,6 +340,9 @@ hipError_t launch_resblock_tail(TailArgs a, hipStream_t st) {
     const long total32 = tail_wgs32 > 0 ? tail_wgs32 : std::max<long>(2048, need32 * a.batch / 8);
     int gx = (int)std::min<long>(need32, std::max<long>(1, std::min<long>(2048, total32 / std::max(1, a.batch))));
     dim3 grid(gx, a.batch);
+    const double el = (double)a.batch * a.pix_per_sample * a.C;
+    LaunchScope ls(st, "resblock_tail_kernel", 10.0 * el, el * ((a.y2_bf16 ? 2.0 : 4.0) + (a.r_bf16 ? 2.0 : 4.0) + (a.out_bf16 ? 2.0 : 4.0)), "<%d> C%d px%ld x %d y2_16 %d", vpl == 3 ? 4 : vpl,
+                   a.C, a.pix_per_sample, a.batch, a.y2_bf16);
     switch (vpl) {
         case 1: hipLaunchKernelGGL(resblock_tail_kernel<1>, grid, dim3(256), 0, st, a); break;
         case 2: hipLaunchKernelGGL(resblock_tail_kernel<2>, grid, dim3(256), 0, st, a); break;
@@ -511,11 +519,15 @@ hipError_t launch_init_conv_mode(int mode, const float* x, const float* w, const
     if (mode == MODE_BF16 && Cin == 1 && K <= 8 && Cout <= 64 && Cout % 4 == 0) {
         const size_t lds = ((23 * 23 * 4 + 15) / 16) * 16 + (size_t)(64 + 256) * (64 * 2 + 16);
         dim3 grid(((W + 15) / 16) * ((H + 15) / 16), B * F);
+        const double px = (double)B * F * H * W;
+        LaunchScope ls(st, "init_conv_mfma_kernel", 2.0 * px * K * K * Cout, px * (4.0 + Cout * (y_bf16 ? 2.0 : 4.0)), "k%d 1->%d %dx%dx%d", K, Cout, B * F, H, W);
         hipLaunchKernelGGL(init_conv_mfma_kernel, grid, dim3(256), lds, st, x, w, bias, y, B, F, H, W, Cout, K, y_bf16);
         return hipGetLastError();
     }
     const int TW = 16 + K - 1;
     dim3 grid(((W + 15) / 16) * ((H + 15) / 16), B * F, (Cout + 15) / 16);
+    const double px = (double)B * F * H * W;
+    LaunchScope ls(st, "init_conv_kernel", 2.0 * px * K * K * Cin * Cout, px * (4.0 * Cin + Cout * (y_bf16 ? 2.0 : 4.0)), "k%d %d->%d %dx%dx%d", K, Cin, Cout, B * F, H, W);
     hipLaunchKernelGGL(init_conv_kernel, grid, dim3(256), (size_t)Cin * TW * TW * 4, st, x, w, bias, y, B, Cin, F, H, W, Cout, K, y_bf16);
     return hipGetLastError();
 }
@@ -594,6 +606,7 @@ hipError_t launch_final_conv(const float* x, const float* w, const float* bias, 
     if (x_bf16 && D % 8 == 0 && D <= 128 && ((D / 8) & (D / 8 - 1)) == 0 && Cout >= 1 && Cout <= 4) {
         const int lpp = D / 8, ppb = 256 / lpp;
         const int blocks = (int)std::min<long>((npix + 4L * ppb - 1) / (4L * ppb), 4096);
+        LaunchScope ls(st, "final_conv16_kernel", 2.0 * npix * D * Cout, (double)npix * (D * 2.0 + Cout * 4.0), "<%d> D%d px%ld", Cout, D, npix);
         switch (Cout) {
             case 1: hipLaunchKernelGGL(final_conv16_kernel<1>, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, lpp); break;
             case 2: hipLaunchKernelGGL(final_conv16_kernel<2>, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, lpp); break;
@@ -609,6 +622,7 @@ hipError_t launch_final_conv(const float* x, const float* w, const float* bias, 
     while (lpp * per < D && lpp < 16) lpp <<= 1;
     const int ppb = 256 / lpp;
     const int blocks = (int)std::min<long>((npix + ppb - 1) / ppb, 4096);
+    LaunchScope ls(st, "final_conv_kernel", 2.0 * npix * D * Cout, (double)npix * (D * (x_bf16 ? 2.0 : 4.0) + Cout * 4.0), "D%d->%d px%ld", D, Cout, npix);
     hipLaunchKernelGGL(final_conv_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, y, npix, D, Cout, lpp, x_bf16);
     return hipGetLastError();
 }
@@ -666,6 +680,7 @@ __global__ __launch_bounds__(256) void time_mlp_kernel(TimeMlpArgs P) {
 }
 
 hipError_t launch_time_mlp(const TimeMlpArgs& a, int B, hipStream_t st) {
+    LaunchScope ls(st, "time_mlp_kernel", 2.0 * B * (a.dim * a.time_dim + (double)a.time_dim * a.time_dim), 4.0 * (a.dim * a.time_dim + (double)a.time_dim * a.time_dim), "dim%d B%d", a.dim, B);
     hipLaunchKernelGGL(time_mlp_kernel, dim3(B), dim3(256), (size_t)(a.dim + a.time_dim) * 4, st, a);
     return hipGetLastError();
 }
@@ -751,10 +766,14 @@ hipError_t launch_resblock_ss(const float* params, const float* temb, const SsLa
     // lin_base (the pre-LayerNorm values, also what the backward reads) is required scratch
     if (!lin_base || nlayers <= 0) return hipErrorInvalidValue;
     const size_t lds = ((size_t)SS_BG * temb_dim + 4 * SS_BG * 64) * 4;
-    hipLaunchKernelGGL(resblock_ss_lin_kernel, dim3(nlayers, (max_n + 63) / 64, (B + SS_BG - 1) / SS_BG), dim3(256), lds, st, params, temb, layers,
-                       lin_base, temb_dim, B);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    {
+        LaunchScope ls(st, "resblock_ss_lin_kernel", 0.0, 0.0, "layers%d B%d", nlayers, B);
+        hipLaunchKernelGGL(resblock_ss_lin_kernel, dim3(nlayers, (max_n + 63) / 64, (B + SS_BG - 1) / SS_BG), dim3(256), lds, st, params, temb, layers,
+                           lin_base, temb_dim, B);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    LaunchScope ls(st, "resblock_ss_norm_kernel", 0.0, 0.0, "layers%d B%d", nlayers, B);
     hipLaunchKernelGGL(resblock_ss_norm_kernel, dim3(B, nlayers), dim3(256), 0, st, params, layers, lin_base, ss_base, B);
     return hipGetLastError();
 }

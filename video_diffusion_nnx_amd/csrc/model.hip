@@ -151,8 +151,7 @@ int model_build(Model* m) {
     if (c.dim < 8 || c.dim % 8 || c.n_mults < 1 || c.n_mults > 8) return vdx_set_error(VDX_ERR_INVALID, "config: dim must be a positive multiple of 8, 1..8 dim_mults", __FILE__, __LINE__);
     if (c.attn_dim_head != 32) return vdx_set_error(VDX_ERR_INVALID, "config: attn_dim_head must be 32", __FILE__, __LINE__);
     if (c.use_sparse_linear_attn && c.attn_heads != 8) return vdx_set_error(VDX_ERR_INVALID, "config: SpatialLinearAttention needs attn_heads == 8", __FILE__, __LINE__);
-    // the fused q|k|v weight gradient (wgrad.hip, split = heads * 32) owns whole 64-wide output tiles per tensor
-    if (c.attn_heads < 1 || (c.attn_heads * 32) % 64) return vdx_set_error(VDX_ERR_INVALID, "config: attn_heads must be even (heads * 32 a multiple of 64)", __FILE__, __LINE__);
+    if (c.attn_heads < 1 || c.attn_heads > 32) return vdx_set_error(VDX_ERR_INVALID, "config: attn_heads must be in 1..32", __FILE__, __LINE__);      // (odd counts: forward only, see vdx_unet_backward)
     if (c.resnet_groups < 1 || c.resnet_groups > 32) return vdx_set_error(VDX_ERR_INVALID, "config: resnet_groups must be in 1..32", __FILE__, __LINE__);
     if (!(c.init_kernel_size & 1)) return vdx_set_error(VDX_ERR_INVALID, "config: init_kernel_size must be odd", __FILE__, __LINE__);
     const int down = 1 << (c.n_mults - 1);
@@ -510,7 +509,10 @@ int model_forward(const Model* m, const float* params, const void* packed, const
     f.sla_ws = w;
     hipError_t e;
 #define VDX_E(x) do { e = (x); if (e != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__); } while (0)
-    VDX_E(hipMemsetAsync(f.stats, 0, stats_bytes, st));
+    {
+        LaunchScope ls(st, "fillBufferAligned", 0.0, (double)stats_bytes, "GroupNorm statistics slabs %zu B", stats_bytes);      // (hipMemsetAsync's kernel)
+        VDX_E(hipMemsetAsync(f.stats, 0, stats_bytes, st));
+    }
     const int S0 = c.image_size, Fr = c.num_frames;
     // time embedding + every ResnetBlock's (scale, shift)   (unet3d.py:288-298, modules.py:233-238)
     {

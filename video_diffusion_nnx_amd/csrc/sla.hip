@@ -893,6 +893,23 @@ __global__ __launch_bounds__(512) void sla_head_kernel(const SlaArgs P, void* __
     }
 }
 
+// instrumentation (vdx.h: vdx_set_launch_hook): algorithmic work of the two halves of a SpatialLinearAttention block over px = NF * N
+// pixels.  ctx half: k, v projections 2 C 512 + context 2 * 256 * 32 FLOP per pixel, reads x; out half: q projection
+// 2 C 256 + ctx^T q 2 * 256 * 32 + to_out 2 * 256 * C (when `with_out`), reads x, writes y (or the per-head output [px][256] bf16).
+namespace {
+struct SlaWork { double flops, bytes; };
+SlaWork sla_work(const SlaArgs& a, int es_w, bool ctx_half, bool out_half, bool with_out) {
+    const double px = (double)a.NF * a.N, eio = a.io_bf16 ? 2.0 : 4.0, ctx_bytes = (double)a.NF * a.heads * 32 * 32 * 4;
+    SlaWork w{0.0, 0.0};
+    if (ctx_half) { w.flops += px * (2.0 * a.C * 512 + 2.0 * 256 * 32); w.bytes += px * a.C * eio + ctx_bytes + es_w * 512.0 * a.C; }
+    if (out_half) {
+        w.flops += px * (2.0 * a.C * 256 + 2.0 * 256 * 32 + (with_out ? 2.0 * 256 * a.C : 0.0));
+        w.bytes += px * a.C * eio + (with_out ? px * a.C * eio : px * 256 * 2.0) + (ctx_half ? 0.0 : ctx_bytes) + es_w * (256.0 * a.C + (with_out ? 256.0 * a.C : 0.0));
+    }
+    return w;
+}
+}  // namespace
+
 hipError_t launch_sla_heads(SlaArgs a, void* O, hipStream_t st) {
     a.CPad = conv_cin_pad(MODE_BF16, a.C);
     if (a.heads != 8 || a.C % 128 || a.N % 16 || !O) return hipErrorInvalidValue;
@@ -906,6 +923,8 @@ hipError_t launch_sla_heads(SlaArgs a, void* O, hipStream_t st) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
+        const SlaWork sw = sla_work(a, 2, true, true, false);
+        LaunchScope ls(st, "sla_head_kernel", sw.flops, sw.bytes, "<io16 %d, %d> C%d N%d NF%d", a.io_bf16, a.N % 64 == 0 ? 4 : 1, a.C, a.N, a.NF);
         hipLaunchKernelGGL(kfn, dim3((unsigned)((chunks + 7) / 8 * 64)), dim3(512), lds, st, a, O, (int)fpb, (int)chunks);
         return hipGetLastError();
     };
@@ -941,6 +960,8 @@ static hipError_t launch_sla_out_t(const SlaArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
     }
     const int tiles = (a.N + 63) / 64;
+    const SlaWork sw = sla_work(a, M::ES, false, true, true);
+    LaunchScope ls(st, "sla_out_kernel", sw.flops, sw.bytes, "<%d, %d> C%d N%d NF%d io16 %d", MODE, TMO, a.C, a.N, a.NF, a.io_bf16);
     hipLaunchKernelGGL(kfn, dim3(a.NF * tiles), dim3(256), lds, st, a);
     return hipGetLastError();
 }
@@ -956,12 +977,19 @@ static hipError_t launch_sla8_t(const SlaArgs& a, hipStream_t st) {
     hipError_t e;
     if (lds_ctx > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(kc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ctx)) != hipSuccess) return e;
     if (lds_out > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void*>(ko), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_out)) != hipSuccess) return e;
-    hipLaunchKernelGGL(kc, dim3(a.NF * a.nchunk), dim3(512), lds_ctx, st, a);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    {
+        const SlaWork sw = sla_work(a, M::ES, true, false, false);
+        LaunchScope ls(st, "sla_ctx8_kernel", sw.flops, sw.bytes, "<%d, %d, %d> C%d N%d NF%d nchunk%d", MODE, NKT, (int)IO16, a.C, a.N, a.NF, a.nchunk);
+        hipLaunchKernelGGL(kc, dim3(a.NF * a.nchunk), dim3(512), lds_ctx, st, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if (a.nchunk > 1) {                                       // (one chunk per frame: sla_ctx8_kernel wrote ctxT itself)
+        LaunchScope ls(st, "sla_combine_kernel", 0.0, (double)a.NF * a.nchunk * a.heads * SLA_PART * 4, "<%d> NF%d nchunk%d", MODE, a.NF, a.nchunk);
         hipLaunchKernelGGL(sla_combine_kernel<MODE>, dim3(a.NF * a.heads), dim3(256), 0, st, a.part, a.ctxT, a.nchunk, a.heads);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
+    const SlaWork sw = sla_work(a, M::ES, false, true, true);
+    LaunchScope ls(st, "sla_out8_kernel", sw.flops, sw.bytes, "<%d, %d, %d, %d, %d> C%d N%d NF%d", MODE, NKT, TMO, TNO, (int)IO16, a.C, a.N, a.NF);
     hipLaunchKernelGGL(ko, dim3(a.NF * a.nchunk), dim3(512), lds_out, st, a);
     return hipGetLastError();
 }
@@ -996,12 +1024,18 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
         if (nkt == 2 && a.C == 128) return launch_sla8_t<MODE, 2, 1, 4, false>(a, st);
     }
     const size_t lds1 = 1024 + (size_t)128 * ROW_STRIDE + (size_t)64 * RSE;
-    hipLaunchKernelGGL(sla_ctx_kernel<MODE>, dim3(((a.NF * a.nchunk + 7) / 8) * 8 * a.heads), dim3(256), lds1, st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sla_combine_kernel<MODE>, dim3(a.NF * a.heads), dim3(256), 0, st, a.part, a.ctxT, a.nchunk, a.heads);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    {
+        const SlaWork sw = sla_work(a, M::ES, true, false, false);
+        LaunchScope ls(st, "sla_ctx_kernel", sw.flops, sw.bytes, "<%d> C%d N%d NF%d nchunk%d io16 %d", MODE, a.C, a.N, a.NF, a.nchunk, a.io_bf16);
+        hipLaunchKernelGGL(sla_ctx_kernel<MODE>, dim3(((a.NF * a.nchunk + 7) / 8) * 8 * a.heads), dim3(256), lds1, st, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    {
+        LaunchScope ls(st, "sla_combine_kernel", 0.0, (double)a.NF * a.nchunk * a.heads * SLA_PART * 4, "<%d> NF%d nchunk%d", MODE, a.NF, a.nchunk);
+        hipLaunchKernelGGL(sla_combine_kernel<MODE>, dim3(a.NF * a.heads), dim3(256), 0, st, a.part, a.ctxT, a.nchunk, a.heads);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if (a.C <= 64) return launch_sla_out_t<MODE, 1>(a, st);
     if (a.C <= 128) return launch_sla_out_t<MODE, 2>(a, st);
     if (a.C <= 256) return launch_sla_out_t<MODE, 4>(a, st);

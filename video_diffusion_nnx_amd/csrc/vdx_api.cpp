@@ -4,21 +4,32 @@
 #include <math.h>
 #include "vdx_internal.h"
 #include "model.h"
+#include "comm.h"
 
 struct vdx_handle {
     vdx::Model model;
     // every argument a captured sampling step bakes in (full pointers: two workspaces / streams never alias one key)
     struct GraphKey { const void* p[12]; unsigned long long seed; int i[4]; size_t ws; float f; };
     // one cached graph per loop kind: 0 = DDPM p_sample_loop, 1 = DDIM
-    struct GraphSlot { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; GraphKey key; } gs[2];
-    void drop_graphs() {
-        for (GraphSlot& g : gs) {
-            if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-            if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+    // `last` = the stream the exec was last launched on: replays may still be running when the graph has to go
+    struct GraphSlot {
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; GraphKey key; hipStream_t last = nullptr;
+        void drop() {
+            if (exec && last) (void)hipStreamSynchronize(last);       // earlier hipGraphLaunch calls of this exec have finished
+            if (exec) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
+            if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+            last = nullptr;
         }
-    }
+    } gs[2];
+    void drop_graphs() { for (GraphSlot& g : gs) g.drop(); }
     vdx::BwdState bwd;
+    vdx::Comm comm;
 };
+
+namespace vdx {
+vdx_launch_hook g_launch_hook = nullptr;
+void* g_launch_hook_user = nullptr;
+}
 
 static thread_local char g_err[512] = "";
 
@@ -44,16 +55,20 @@ static int run_steps(vdx_handle* h, int which, const vdx_handle::GraphKey& key, 
         int rc = step();                                    // eager first step (also sets kernel attributes before capture)
         if (rc != VDX_OK) return rc;
         done = 1;
-        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
-        if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+        g.drop();
         VDX_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         rc = step();
         hipError_t ce = hipStreamEndCapture(st, &g.graph);
-        if (rc != VDX_OK) return rc;
-        if (ce != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(ce), __FILE__, __LINE__);
-        VDX_HIP(hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        if (rc != VDX_OK || ce != hipSuccess) {             // a failed capture leaves no half-built graph behind
+            if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+            if (rc != VDX_OK) return rc;
+            return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(ce), __FILE__, __LINE__);
+        }
+        hipError_t ie = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) { g.exec = nullptr; g.drop(); return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(ie), __FILE__, __LINE__); }
         g.key = key;
     }
+    g.last = st;
     for (int i = done; i < nsteps; ++i) VDX_HIP(hipGraphLaunch(g.exec, st));
     return VDX_OK;
 }
@@ -72,7 +87,7 @@ int vdx_pack_conv_weights(int mode, const float* kernel, void* packed, int taps,
     return VDX_OK;
 }
 
-void vdx_set_conv_launch_hook(vdx_conv_launch_hook hook, void* user) { vdx::set_conv_launch_hook(hook, user); }
+void vdx_set_launch_hook(vdx_launch_hook hook, void* user) { vdx::g_launch_hook = hook; vdx::g_launch_hook_user = user; }
 
 size_t vdx_gn_stats_bytes(int batch, int groups) { return (size_t)batch * 32 /*GN_SLOTS*/ * groups * 2 * sizeof(double); }
 
@@ -169,7 +184,7 @@ int vdx_final_conv(const float* x, const float* kernel, const float* bias, float
 int vdx_time_mlp(const int* time, const float* w1, const float* b1, const float* w2, const float* b2, int dim,
                  const float* cond, const float* null_cond_emb, const unsigned char* cond_mask, int null_all, int cond_dim,
                  float* temb, int batch, void* stream) {
-    if (!time || !w1 || !b1 || !w2 || !b2 || !temb || dim < 4 || (dim % 4)) VDX_FAIL(VDX_ERR_INVALID, "time_mlp: bad argument (dim must be a multiple of 4)");
+    if (!time || !w1 || !b1 || !w2 || !b2 || !temb || dim < 4 || (dim % 4)) VDX_FAIL(VDX_ERR_INVALID, "time_mlp: bad argument (dim must be a multiple of 4; Unet3D itself needs dim % 8 == 0)");
     if (cond_dim && (!cond || !null_cond_emb)) VDX_FAIL(VDX_ERR_INVALID, "time_mlp: cond missing");
     vdx::TimeMlpArgs a;
     memset(&a, 0, sizeof(a));
@@ -192,7 +207,7 @@ int vdx_attention_forward_ex(int mode, const float* x, float* y, const void* wqk
     if (fp8_core && mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "attention: the fp8 core needs VDX_MODE_BF16");
     if (!x || !y || !wqkv_packed || !bqkv || !wo_packed || !bo) VDX_FAIL(VDX_ERR_INVALID, "attention: null tensor");
     if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16 && mode != VDX_MODE_F16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
-    if (c % 4 || c > 512 || heads < 1) VDX_FAIL(VDX_ERR_INVALID, "attention: C must be a multiple of 4 and <= 512");
+    if (c % 4 || c > 1024 || heads < 1) VDX_FAIL(VDX_ERR_INVALID, "attention: C must be a multiple of 4 and <= 1024");
     vdx::AttnArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.y = y; a.wqkv = wqkv_packed; a.bqkv = bqkv; a.wo = wo_packed; a.bo = bo; a.C = c; a.heads = heads;
@@ -215,7 +230,7 @@ int vdx_sla_forward(int mode, const float* x, float* y, const void* wq_packed, c
                     const void* wo_packed, void* workspace, int batch, int frames, int h, int w, int c, int heads, void* stream) {
     if (!x || !y || !wq_packed || !wk_packed || !wv_packed || !wo_packed || !workspace) VDX_FAIL(VDX_ERR_INVALID, "sla: null tensor");
     if (mode != VDX_MODE_F32 && mode != VDX_MODE_BF16 && mode != VDX_MODE_F16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");
-    if (heads != 8 || c % 4 || c > 512) VDX_FAIL(VDX_ERR_INVALID, "sla: needs 8 heads, C multiple of 4 and <= 512");
+    if (heads != 8 || c % 4 || c > 1024) VDX_FAIL(VDX_ERR_INVALID, "sla: needs 8 heads, C multiple of 4 and <= 1024");
     vdx::SlaArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.y = y; a.wq = wq_packed; a.wk = wk_packed; a.wv = wv_packed; a.wo = wo_packed; a.workspace = workspace;
@@ -256,6 +271,7 @@ int vdx_create(const vdx_config* cfg, vdx_handle** out) {
 void vdx_destroy(vdx_handle* h) {
     if (!h) return;
     h->drop_graphs();
+    vdx::comm_destroy(&h->comm);
     vdx::bwd_state_free(&h->bwd);
     if (h->model.d_ss_layers) (void)hipFree(h->model.d_ss_layers);
     if (h->model.d_pack_jobs) (void)hipFree(h->model.d_pack_jobs);
@@ -435,12 +451,15 @@ int vdx_ddim_step(const float* x, const float* eps_hat, float* out, const float*
     return VDX_OK;
 }
 
-int vdx_ddim_sample_loop(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
-                         uint64_t* step_dev, const float* alphas_cumprod, const int* seq, int seq_len, int nsteps, const float* cond,
-                         int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream) {
+int vdx_ddim_sample_loop_dyn(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
+                             uint64_t* step_dev, const float* alphas_cumprod, const int* seq, int seq_len, int nsteps, const float* cond,
+                             int clip_denoised, const float* tables, int timesteps, float percentile, float* thres_buf, void* workspace,
+                             size_t workspace_bytes, int batch, int use_graph, void* stream) {
     if (!h || !params || !packed || !img || !eps_buf || !t_dev || !step_dev || !alphas_cumprod || !seq || !workspace) VDX_FAIL(VDX_ERR_INVALID, "ddim_sample_loop: null argument");
     if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "ddim_sample_loop: handle was created without a GPU");
     if (seq_len < 1 || nsteps < 0 || nsteps > seq_len) VDX_FAIL(VDX_ERR_INVALID, "ddim_sample_loop: nsteps out of range");
+    const bool dyn = percentile > 0.f && clip_denoised;
+    if (dyn && (!thres_buf || !tables || timesteps < 1 || percentile > 1.f)) VDX_FAIL(VDX_ERR_INVALID, "ddim_sample_loop: dynamic threshold needs tables, thres_buf and a percentile in (0, 1]");
     const vdx::Model& m = h->model;
     const long per_sample = (long)m.cfg.channels * m.cfg.num_frames * m.cfg.image_size * m.cfg.image_size;
     if (m.out_dim != m.cfg.channels) VDX_FAIL(VDX_ERR_INVALID, "ddim_sample_loop: out_dim must equal channels");
@@ -448,8 +467,10 @@ int vdx_ddim_sample_loop(vdx_handle* h, const float* params, const void* packed,
     auto step = [&]() -> int {
         int rc = vdx::model_forward(&m, params, packed, img, t_dev, cond, nullptr, 0, eps_buf, workspace, workspace_bytes, batch, st);
         if (rc != VDX_OK) return rc;
-        hipError_t e = vdx::launch_ddim_step(img, eps_buf, img, alphas_cumprod, seq, reinterpret_cast<const unsigned long long*>(step_dev), nullptr,
-                                             clip_denoised, batch, m.cfg.channels, per_sample, st);
+        hipError_t e = hipSuccess;
+        if (dyn) e = vdx::launch_dyn_thres(img, eps_buf, t_dev, tables, timesteps, percentile, thres_buf, batch, m.cfg.channels, per_sample, st);
+        if (e == hipSuccess) e = vdx::launch_ddim_step(img, eps_buf, img, alphas_cumprod, seq, reinterpret_cast<const unsigned long long*>(step_dev),
+                                                       dyn ? thres_buf : nullptr, clip_denoised, batch, m.cfg.channels, per_sample, st);
         if (e == hipSuccess) e = vdx::launch_ddim_advance(t_dev, batch, seq, reinterpret_cast<unsigned long long*>(step_dev), st);
         if (e != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(e), __FILE__, __LINE__);
         return VDX_OK;
@@ -457,9 +478,17 @@ int vdx_ddim_sample_loop(vdx_handle* h, const float* params, const void* packed,
     vdx_handle::GraphKey key;
     memset(&key, 0, sizeof(key));
     key.p[0] = params; key.p[1] = packed; key.p[2] = img; key.p[3] = eps_buf; key.p[4] = t_dev; key.p[5] = step_dev;
-    key.p[6] = alphas_cumprod; key.p[7] = cond; key.p[8] = workspace; key.p[9] = stream; key.p[10] = seq;
-    key.i[0] = seq_len; key.i[1] = clip_denoised | (h->model.act16 << 8); key.i[2] = batch; key.ws = workspace_bytes;
+    key.p[6] = alphas_cumprod; key.p[7] = cond; key.p[8] = workspace; key.p[9] = stream; key.p[10] = seq; key.p[11] = dyn ? (const void*)thres_buf : nullptr;
+    key.i[0] = seq_len; key.i[1] = clip_denoised | (h->model.act16 << 8); key.i[2] = batch; key.i[3] = dyn ? timesteps : 0; key.ws = workspace_bytes;
+    key.f = dyn ? percentile : 0.f; key.seed = dyn ? (unsigned long long)(uintptr_t)tables : 0ull;
     return run_steps(h, 1, key, nsteps, use_graph, st, step);
+}
+
+int vdx_ddim_sample_loop(vdx_handle* h, const float* params, const void* packed, float* img, float* eps_buf, int* t_dev,
+                         uint64_t* step_dev, const float* alphas_cumprod, const int* seq, int seq_len, int nsteps, const float* cond,
+                         int clip_denoised, void* workspace, size_t workspace_bytes, int batch, int use_graph, void* stream) {
+    return vdx_ddim_sample_loop_dyn(h, params, packed, img, eps_buf, t_dev, step_dev, alphas_cumprod, seq, seq_len, nsteps, cond, clip_denoised,
+                                    nullptr, 0, 0.f, nullptr, workspace, workspace_bytes, batch, use_graph, stream);
 }
 
 int vdx_pack_conv_weights_t(int mode, const float* kernel, void* packed, int taps, int cin, int cout, void* stream) {
@@ -585,6 +614,8 @@ int vdx_unet_backward(vdx_handle* h, const float* params, const void* packed, co
     if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "unet_backward: handle was created without a GPU");
     if (h->model.act16) VDX_FAIL(VDX_ERR_STATE, "unet_backward: the forward ran with bf16 activation storage; the backward reads fp32 slots");
     if (h->model.attn_fp8) VDX_FAIL(VDX_ERR_STATE, "unet_backward: fp8 attention is a forward (sampling) option; the backward differentiates the bf16 cores");
+    // the fused q|k|v weight gradient (wgrad.hip, split = heads * 32) owns whole 64-wide output tiles per tensor
+    if ((h->model.cfg.attn_heads * 32) % 64) VDX_FAIL(VDX_ERR_INVALID, "unet_backward: attn_heads must be even (heads * 32 a multiple of 64); odd head counts are forward / sampling only");
     return vdx::model_backward(&h->model, &h->bwd, params, packed, packed_t, x, time, cond, cond_mask, null_all, d_out, fwd_workspace,
                                bwd_workspace, bwd_workspace_bytes, grads, stage_hi, stage_lo, batch, (hipStream_t)stream);
 }
@@ -599,6 +630,30 @@ int vdx_adam_ema_step(float* params, const float* grads, float* m, float* v, flo
                       float eps, long step_count, float grad_scale, int do_ema, float ema_decay, void* stream) {
     if (!params || !grads || !m || !v || (do_ema && !ema) || n < 1 || step_count < 0) VDX_FAIL(VDX_ERR_INVALID, "adam_ema_step: bad argument");
     VDX_HIP(vdx::launch_adam_ema(params, grads, m, v, ema, n, lr, b1, b2, eps, step_count, grad_scale, do_ema, ema_decay, (hipStream_t)stream));
+    return VDX_OK;
+}
+
+int vdx_comm_unique_id(void* unique_id_out) {
+    if (!unique_id_out) VDX_FAIL(VDX_ERR_INVALID, "comm_unique_id: null argument");
+    return vdx::comm_unique_id(unique_id_out);
+}
+
+int vdx_comm_init(vdx_handle* h, int rank, int world, const void* unique_id) {
+    if (!h || !unique_id || world < 1 || rank < 0 || rank >= world) VDX_FAIL(VDX_ERR_INVALID, "comm_init: bad argument");
+    return vdx::comm_init(&h->comm, rank, world, unique_id);
+}
+
+int vdx_allreduce_bucket(vdx_handle* h, float* ptr, size_t count, void* stream) {
+    if (!h || !ptr) VDX_FAIL(VDX_ERR_INVALID, "allreduce_bucket: null argument");
+    if (count == 0) return VDX_OK;
+    return vdx::comm_allreduce(&h->comm, ptr, count, (hipStream_t)stream);
+}
+
+int vdx_comm_world(const vdx_handle* h) { return h ? h->comm.world : 1; }
+
+int vdx_comm_destroy(vdx_handle* h) {
+    if (!h) VDX_FAIL(VDX_ERR_INVALID, "comm_destroy: null handle");
+    vdx::comm_destroy(&h->comm);
     return VDX_OK;
 }
 

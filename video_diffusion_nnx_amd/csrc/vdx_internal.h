@@ -1,13 +1,35 @@
 // Internal (non-ABI) declarations shared by the kernel translation units and the host runtime.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdarg.h>
 #include <stddef.h>
+#include <stdio.h>
 #include <algorithm>
 #include "../../include/vdx.h"
 
 int vdx_set_error(int code, const char* msg, const char* file, int line);
 
 namespace vdx {
+
+// Instrumentation hook (vdx.h: vdx_set_launch_hook).  A LaunchScope brackets ONE kernel launch: its constructor calls the hook with
+// phase 0, its destructor with phase 1.  Costs one load + branch when no hook is installed.
+extern vdx_launch_hook g_launch_hook;
+extern void* g_launch_hook_user;
+struct LaunchScope {
+    vdx_launch_info info; char desc[192]; hipStream_t st; bool on;
+    LaunchScope(hipStream_t s, const char* kernel, double flops, double bytes, const char* fmt, ...) __attribute__((format(printf, 6, 7))) : st(s), on(g_launch_hook != nullptr) {
+        if (!on) return;
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(desc, sizeof(desc), fmt, ap);
+        va_end(ap);
+        info.kernel = kernel; info.shape = desc; info.flops = flops; info.bytes = bytes;
+        g_launch_hook(g_launch_hook_user, 0, &info, st);
+    }
+    ~LaunchScope() { if (on && g_launch_hook) g_launch_hook(g_launch_hook_user, 1, &info, st); }
+    LaunchScope(const LaunchScope&) = delete;
+    LaunchScope& operator=(const LaunchScope&) = delete;
+};
 
 // Arguments of conv_igemm_kernel (POD, passed by value).  Caller fills the first block; launch_conv
 // completes the geometry.
@@ -224,7 +246,6 @@ size_t conv_packed_bytes(int mode, int taps, int Cin, int Cout);
 int conv_cin_pad(int mode, int Cin);
 hipError_t launch_pack_weights(int mode, const float* src, void* dst, int taps, int Cin, int Cout, hipStream_t st);
 hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st);
-void set_conv_launch_hook(vdx_conv_launch_hook hook, void* user);
 int conv3x3_ws_geo(const ConvArgs& a);
 bool conv4x4_ws_eligible(int mode, const ConvArgs& a);     // Downsample / Upsample of the wide levels on the weight-streaming machinery
 hipError_t launch_conv4x4_ws(const ConvArgs& a, hipStream_t st);       // 0 / 8 / 16: the GEO template argument launch_conv3x3_ws will use

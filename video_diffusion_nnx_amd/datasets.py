@@ -58,6 +58,7 @@ class DevicePrefetcher:
         self.on_gpu = self.device.type == 'cuda' and torch.cuda.is_available()
         self.stream = torch.cuda.Stream(device=self.device) if self.on_gpu else None
         self._pinned = [None, None]                                   # two pinned staging buffers, used alternately
+        self._copied = [None, None]                                   # event behind the last H2D copy OUT of each buffer
         self._k = 0
         self._next = None
         self._stage()
@@ -74,12 +75,16 @@ class DevicePrefetcher:
         buf = self._pinned[self._k]
         if buf is None or buf.shape != host.shape:
             buf = self._pinned[self._k] = torch.empty(host.shape, dtype=torch.float32).pin_memory()
+        k = self._k
         self._k ^= 1
+        if self._copied[k] is not None:
+            self._copied[k].synchronize()                             # the DMA that read this buffer two batches ago has finished (almost always already true)
         buf.copy_(host)
         with torch.cuda.stream(self.stream):
             dev = buf.to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
+        self._copied[k] = ev
         self._next = (dev, ev)
 
     def __iter__(self):

@@ -29,6 +29,8 @@ vdx_p_sample_loop_dyn = L._sig('vdx_p_sample_loop_dyn', C.c_int, [_vp] * 8 + [C.
 vdx_dynamic_threshold = L._sig('vdx_dynamic_threshold', C.c_int, [_vp] * 4 + [C.c_int, C.c_float, _vp, C.c_int, C.c_int, C.c_long, _vp])
 vdx_ddim_step = L._sig('vdx_ddim_step', C.c_int, [_vp] * 7 + [C.c_int, C.c_int, C.c_int, C.c_long, _vp])
 vdx_ddim_sample_loop = L._sig('vdx_ddim_sample_loop', C.c_int, [_vp] * 9 + [C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int, _vp])
+vdx_ddim_sample_loop_dyn = L._sig('vdx_ddim_sample_loop_dyn', C.c_int, [_vp] * 9 + [C.c_int, C.c_int, _vp, C.c_int, _vp, C.c_int, C.c_float, _vp, _vp, C.c_size_t,
+                                                                       C.c_int, C.c_int, _vp])
 
 
 def ddim_time_sequence(timesteps: int, steps: int) -> np.ndarray:
@@ -83,6 +85,20 @@ def split_key(key: int, num: int = 2):
         z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
         out.append(z ^ (z >> 31))
     return out
+
+
+def dist_rank_world():
+    """(rank, world) of the default torch.distributed group, (0, 1) outside one."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_key(key: int, rank: int, world: int) -> int:
+    """Philox seed of rank `rank`'s shard of a data-parallel sampling batch: a function of (key, rank) only, so the videos a rank
+    draws do not depend on how many other ranks there are; one rank keeps `key` itself."""
+    return int(key) & 0xFFFFFFFFFFFFFFFF if world == 1 else split_key(key, rank + 1)[-1]
 
 
 def extract(a: torch.Tensor, t: torch.Tensor, x_shape) -> torch.Tensor:
@@ -262,7 +278,8 @@ class GaussianDiffusion:
                         t = torch.full((B,), int(seq_host[k]), dtype=torch.int32, device=self.device)
                         eps_hat = unet.forward_with_cond_scale(img, t, cond=cond, cond_scale=cond_scale)
                         step_dev.fill_(k)
-                        L.check(vdx_ddim_step(L.ptr(img), L.ptr(eps_hat), L.ptr(img), L.ptr(self.alphas_cumprod), L.ptr(seq), L.ptr(step_dev), 0, 1,
+                        thres = self._dynamic_threshold(img, t, eps_hat) if self.use_dynamic_thres else None
+                        L.check(vdx_ddim_step(L.ptr(img), L.ptr(eps_hat), L.ptr(img), L.ptr(self.alphas_cumprod), L.ptr(seq), L.ptr(step_dev), L.ptr(thres), 1,
                                               B, self.channels, self._per_sample(img), L.stream_ptr()))
                 else:
                     condd = None if (cond is None or not unet.has_cond) else self._dev(cond)
@@ -272,9 +289,12 @@ class GaussianDiffusion:
                     eps = torch.empty(B, self.num_frames, self.image_size, self.image_size, unet.out_dim, dtype=torch.float32, device=self.device)
                     t_dev = torch.full((B,), int(seq_host[0]), dtype=torch.int32, device=self.device)
                     step_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
-                    L.check(vdx_ddim_sample_loop(h.ptr, L.ptr(unet.flat_params), L.ptr(unet.packed()), L.ptr(img), L.ptr(eps), L.ptr(t_dev),
-                                                 L.ptr(step_dev), L.ptr(self.alphas_cumprod), L.ptr(seq), steps, steps, L.ptr(condd), 1,
-                                                 L.ptr(ws), ws.numel(), B, int(use_graph), L.stream_ptr()))
+                    thres = torch.empty(B, dtype=torch.float32, device=self.device) if self.use_dynamic_thres else None
+                    L.check(vdx_ddim_sample_loop_dyn(h.ptr, L.ptr(unet.flat_params), L.ptr(unet.packed()), L.ptr(img), L.ptr(eps), L.ptr(t_dev),
+                                                     L.ptr(step_dev), L.ptr(self.alphas_cumprod), L.ptr(seq), steps, steps, L.ptr(condd), 1,
+                                                     L.ptr(self._ptab), self.num_timesteps,
+                                                     float(self.dynamic_thres_percentile) if self.use_dynamic_thres else 0.0, L.ptr(thres),
+                                                     L.ptr(ws), ws.numel(), B, int(use_graph), L.stream_ptr()))
                 out = torch.empty_like(img)
                 L.check(vdx_affine(L.ptr(img), L.ptr(out), img.numel(), 0.5, 0.5, L.stream_ptr()))     # unnormalize_img
         finally:
@@ -283,12 +303,24 @@ class GaussianDiffusion:
         return out
 
     def sample(self, key, cond=None, cond_scale: float = 1.0, batch_size: int = 16, *, ddim_steps: Optional[int] = None, **kw):
-        """reference :323-357.  ddim_steps (extension): sample with an S-step DDIM chain instead of the T-step ancestral one."""
+        """reference :323-357.  ddim_steps (extension): sample with an S-step DDIM chain instead of the T-step ancestral one.
+
+        Data parallel (reference :278-298: the batch is split over the local devices, `P('data')`): inside an initialised
+        torch.distributed group of W > 1 ranks, `batch_size` (and `cond`) describe the GLOBAL batch; rank r draws videos
+        [r * per, (r + 1) * per), per = batch_size / W, from its own Philox stream shard_key(key, r) and returns ITS shard --
+        no data-path collective.  W = 1 uses `key` itself (single-process behaviour unchanged)."""
         if is_list_str(cond):
             raise NotImplementedError('text -> BERT embedding needs the external video_diffusion_pytorch.text (network fetch); '
                                       'pass a ready [B, 768] tensor instead')
         if cond is not None:
             batch_size = cond.shape[0]
+        rank, world = dist_rank_world()
+        if world > 1:
+            assert batch_size % world == 0, 'batch_size must be divisible by number of devices'      # as reference trainer.py:163
+            per = batch_size // world
+            batch_size, key = per, shard_key(key, rank, world)
+            if cond is not None:
+                cond = cond[rank * per:(rank + 1) * per]
         shape = (batch_size, self.channels, self.num_frames, self.image_size, self.image_size)
         if ddim_steps:
             return self.ddim_sample_loop(shape, key, steps=int(ddim_steps), cond=cond, cond_scale=cond_scale, **kw)

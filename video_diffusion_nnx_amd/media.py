@@ -20,8 +20,9 @@ def video_array_to_gif(arr, path, duration=120, loop=0, optimize=True):
     return frames
 
 
-def videos_to_uint8(videos):
-    """sample.py:106-110: 'b c f h w -> b f h w c', min-max over the WHOLE batch (Q19), * 255 -> uint8."""
+def videos_to_uint8(videos, lo_hi=None):
+    """sample.py:106-110: 'b c f h w -> b f h w c', min-max over the WHOLE batch (Q19), * 255 -> uint8.  lo_hi: the extrema of the
+    GLOBAL batch when `videos` is one rank's shard of it."""
     v = np.asarray(videos).transpose(0, 2, 3, 4, 1)
-    lo, hi = v.min(), v.max()
+    lo, hi = (v.min(), v.max()) if lo_hi is None else lo_hi
     return ((v - lo) / (hi - lo) * 255).astype(np.uint8)

@@ -38,7 +38,6 @@ def run_train_step(tr, batch: torch.Tensor, step: int, t: torch.Tensor = None, n
 
     `t` [B] / `noise` [B,C,F,H,W] override this rank's own draws (the reference threads `noise` through p_losses the same way,
     gaussian_diffusion.py:423-445); the data-parallel tests use them to give N ranks the shards of ONE global draw."""
-    from .trainer import GradBucketReducer
     gd, unet = tr.model, tr.unet
     dev = tr.device
     x = torch.as_tensor(batch).to(dev, torch.float32).contiguous()
@@ -65,7 +64,7 @@ def run_train_step(tr, batch: torch.Tensor, step: int, t: torch.Tensor = None, n
     d_eps = torch.empty_like(eps_hat)
     L.check(vdx_loss_grad(L.ptr(eps_hat), L.ptr(noise), L.ptr(d_eps), B, gd.channels, fhw, l2, L.stream_ptr()))
     # reverse pass stage by stage; finished gradient buckets are all-reduced (RCCL) while earlier stages still run
-    reducer = GradBucketReducer(tr.grads, tr.buckets)
+    reducer = tr.make_reducer()
     ns = unet.num_stages
     for stage in range(ns - 1, -1, -1):
         unet.backward(d_eps, tr.grads, stage, stage)

@@ -90,7 +90,40 @@ class GradBucketReducer:
         self._work, self._next = [], 0
 
 
+class AbiBucketReducer:
+    """GradBucketReducer's contract with the collective behind the C ABI: each finished bucket goes through vdx_allreduce_bucket
+    (RCCL communicator owned by the vdx handle, csrc/comm.cpp) on a side stream that waits for the stage's kernels through an event;
+    the caller's stream waits for the side stream in finish().  SURVEY 8(b): vdx_comm_init / vdx_allreduce_bucket."""
+
+    def __init__(self, flat_grads: torch.Tensor, buckets, handle, world: int, comm_stream):
+        self.flat, self.buckets, self.h, self.world, self.cs = flat_grads, list(buckets), handle, world, comm_stream
+        self.enabled = True
+        self._next = 0
+
+    def stage_done(self, stage: int):
+        from .unet3d import vdx_allreduce_bucket
+        from . import _lib as L
+        ready = []
+        while self._next < len(self.buckets) and self.buckets[self._next][2] >= stage:
+            ready.append(self.buckets[self._next]); self._next += 1
+        if not ready or not self.enabled:
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.flat.device))
+        self.cs.wait_event(ev)
+        for lo, hi, _ in ready:
+            L.check(vdx_allreduce_bucket(self.h.ptr, self.flat.data_ptr() + 4 * lo, hi - lo, self.cs.cuda_stream))
+
+    def finish(self):
+        self.stage_done(-1)
+        torch.cuda.current_stream(self.flat.device).wait_stream(self.cs)
+        self._next = 0
+
+
 class Trainer:
+    # 'torch': torch.distributed.all_reduce per bucket (RCCL under the nccl backend; gloo in the CPU / one-GPU tests).
+    # 'abi': the communicator inside libvdx.so (vdx_comm_init / vdx_allreduce_bucket); needs a CUDA device.  VDX_COMM overrides.
+    comm_backend = os.environ.get('VDX_COMM', 'torch')
     # gradient all-reduce bucket size (floats): >= 16 MB per RCCL call keeps every xGMI ring step bandwidth-bound; the
     # constructor signature stays the reference's, so this is a class attribute
     min_bucket_floats = 4 << 20
@@ -190,6 +223,34 @@ class Trainer:
             save_checkpoint(self.ckpt_manager, self.unet.state_dict(), ema_sd, step)
         except Exception as e:                                   # reference: log and continue (trainer.py:595-602)
             logging.error(f'Error saving checkpoint at step {step}: {e}')
+
+    def _abi_comm(self):
+        """Joins (once) the RCCL communicator of the training handle: rank 0 creates the unique id, the group's own channel carries it."""
+        if getattr(self, '_abi', None) is None:
+            import ctypes as C
+            import torch.distributed as dist
+            from .unet3d import vdx_comm_init, vdx_comm_unique_id
+            from . import _lib as L
+            h = self.unet.handle(self.model.num_frames, self.model.image_size)
+            buf = C.create_string_buffer(128)
+            if self.rank == 0:
+                L.check(vdx_comm_unique_id(buf))
+            box = [bytes(buf.raw)]
+            if self.dist_on and self.world > 1:
+                dist.broadcast_object_list(box, src=0)
+            L.check(vdx_comm_init(h.ptr, self.rank, self.world, box[0]))
+            self._abi = (h, torch.cuda.Stream(device=self.device))
+        return self._abi
+
+    def make_reducer(self):
+        if self.comm_backend == 'abi':
+            h, cs = self._abi_comm()
+            red = AbiBucketReducer(self.grads, self.buckets, h, self.world, cs)
+        else:
+            red = GradBucketReducer(self.grads, self.buckets)
+        if not getattr(self, 'comm_enabled', True):              # timing aid (bench.py: the same step without the collective)
+            red.enabled = False
+        return red
 
     def train_step(self, batch: torch.Tensor, step: int, t=None, noise=None) -> torch.Tensor:
         """One `_pjit_train_step` on this rank's shard of the batch.  Returns the (device) scalar loss of the shard.

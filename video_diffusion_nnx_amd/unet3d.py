@@ -64,6 +64,11 @@ vdx_packed_bwd_bytes = L._sig('vdx_packed_bwd_bytes', C.c_size_t, [_vp])
 vdx_pack_params_bwd = L._sig('vdx_pack_params_bwd', C.c_int, [_vp, _vp, _vp, _vp])
 vdx_bwd_workspace_bytes = L._sig('vdx_bwd_workspace_bytes', C.c_size_t, [_vp, C.c_int])
 vdx_unet_backward = L._sig('vdx_unet_backward', C.c_int, [_vp] * 7 + [_vp, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp, C.c_int, C.c_int, C.c_int, _vp])
+vdx_comm_unique_id = L._sig('vdx_comm_unique_id', C.c_int, [C.c_char_p])
+vdx_comm_init = L._sig('vdx_comm_init', C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p])
+vdx_allreduce_bucket = L._sig('vdx_allreduce_bucket', C.c_int, [_vp, _vp, C.c_size_t, _vp])
+vdx_comm_world = L._sig('vdx_comm_world', C.c_int, [_vp])
+vdx_comm_destroy = L._sig('vdx_comm_destroy', C.c_int, [_vp])
 vdx_unet_forward = L._sig('vdx_unet_forward', C.c_int, [_vp] * 7 + [C.c_int, _vp, _vp, C.c_size_t, C.c_int, _vp])
 
 
