@@ -70,14 +70,19 @@ def n_shape_reference():
 # f32: exact-f32 MFMA products, fp32 storage.  bf16: bf16 MFMA operands everywhere (forward, data and weight gradients,
 # attention cores), fp32 accumulate; measured 1.35e-2 over all 35.7 M parameters at this shape (r02; worst tensors: the q/k
 # projections of the C = 256 / 512 temporal attention at 6-7e-2), stated 2.5e-2.
-@pytest.mark.parametrize('mode,tol', [('f32', 2e-4), ('bf16', 2.5e-2)])
+# bf16+act16: the training configuration of Trainer (round 3) -- the forward additionally stores every inter-kernel activation as bf16
+# (vdx_set_activation_storage(h, 2)) and the backward reads those bf16 slots; stated 3e-2.
+@pytest.mark.parametrize('mode,tol', [('f32', 2e-4), ('bf16', 2.5e-2), ('bf16+act16', 3e-2)])
 def test_unet_backward_north_star_shape(n_shape_reference, mode, tol):
     from video_diffusion_nnx_amd.unet3d import Unet3D
     cfg, p64, x, t, d_out, ref_out, ref_grads = n_shape_reference
+    act16 = mode.endswith('+act16')
+    mode = mode.split('+')[0]
     m = Unet3D(rngs=0, mode=mode, **N_KW)
     m.load_state_dict({k: v.float() for k, v in p64.items()})
+    m.act_bf16 = 2 if act16 else False
     y = m(x, t)
-    assert _rel(y.cpu().double(), ref_out) < (5e-5 if mode == 'f32' else 2e-2)
+    assert _rel(y.cpu().double(), ref_out) < (5e-5 if mode == 'f32' else 3e-2 if act16 else 2e-2)
     grads = torch.zeros_like(m.flat_params)
     m.backward(d_out.to(m.device), grads)
     torch.cuda.synchronize()
@@ -160,6 +165,9 @@ def test_bench_batch64_bf16_storage_spot_check():
 # (c) config_v1_0: one p_losses step (loss + gradients) at the YAML's shape and at BASELINE's wording of it
 # ------------------------------------------------------------------------------------------------------------------
 
+_P_LOSSES_REF = {}
+
+
 def _p_losses_step(tmp_path, ukw, frames, size, T, B, mode, tol_loss, tol_grad):
     from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
     from video_diffusion_nnx_amd.trainer import Trainer
@@ -181,7 +189,10 @@ def _p_losses_step(tmp_path, ukw, frames, size, T, B, mode, tol_loss, tol_grad):
         ref = DiffusionRef(lambda a, b: R.unet_forward(params, cfg, a, b), image_size=size, num_frames=frames, channels=1,
                            timesteps=T, loss_type='l2', dtype=torch.float64)
         return ref.loss(batch.double(), t, noise)
-    ref_loss, ref_grads = train_ref.loss_and_grads(p0, loss_fn)
+    key = (repr(sorted(ukw.items())), frames, size, T, B, tuple(t.tolist()), int(tr.last_noise_key))
+    if key not in _P_LOSSES_REF:                               # one fp64 autograd pass per configuration, shared by the arithmetic modes
+        _P_LOSSES_REF[key] = train_ref.loss_and_grads(p0, loss_fn)
+    ref_loss, ref_grads = _P_LOSSES_REF[key]
     assert abs(loss_dev.item() - ref_loss.item()) < tol_loss * max(1.0, abs(ref_loss.item())), (loss_dev.item(), ref_loss.item())
     total = _rel(_got_flat(unet, tr.grads), _flat(unet, ref_grads))
     print(f'p_losses step {ukw} {frames}f x {size} B={B} {mode}: loss {loss_dev.item():.6f} (ref {ref_loss.item():.6f}), grad rel-L2 {total:.3e}')
@@ -230,27 +241,35 @@ def test_train_cli_config_v1_0_as_written(tmp_path):
 # (d) cond_dim = 768 through the whole dim-64 network, with classifier-free guidance
 # ------------------------------------------------------------------------------------------------------------------
 
+@pytest.fixture(scope='module')
+def text_cond_reference():
+    """fp64 oracle of the guided forward (two passes), shared by the three arithmetic variants."""
+    kw = dict(dim=64, channels=1, cond_dim=768)
+    cfg = R.UnetConfig(**kw)
+    p = R.random_params(cfg, seed=13, dtype=torch.float64)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 1, 16, 64, 64, generator=g)
+    t = torch.tensor([640])
+    cond = torch.randn(1, 768, generator=g)
+    with torch.no_grad():
+        ref = R.forward_with_cond_scale(p, cfg, x.double(), t, cond=cond.double(), cond_scale=2.0)
+    return p, cfg, x, t, cond, ref
+
+
 @pytest.mark.parametrize('mode,tol', [('f32', 5e-5), ('bf16', 2e-2), ('bf16+fp8attn', 6e-2)])
-def test_text_cond_768_cfg_forward_dim64(mode, tol):
+def test_text_cond_768_cfg_forward_dim64(text_cond_reference, mode, tol):
     """BASELINE.json configs[4]: use_bert_text_cond (cond_dim 768), 16f x 64 x 64, cond_scale 2 (the two forwards as one 2B batch).
     The conditioning vector enters through every ResnetBlock's time MLP (temb_dim = 256 + 768).  'bf16+fp8attn' = the configuration's
     "fp8 attention QK^T / PV": every temporal attention block (16 tokens) runs its core on e4m3 operands (vdx_set_attention_fp8; the
     64-token spatial block keeps bf16); no reference counterpart, checked against the fp64 oracle: measured 4.0e-2 with the guidance extrapolation (bf16: 1.2e-2)."""
     from video_diffusion_nnx_amd.unet3d import Unet3D
-    kw = dict(dim=64, channels=1, cond_dim=768)
-    cfg = R.UnetConfig(**kw)
-    p = R.random_params(cfg, seed=13, dtype=torch.float64)
+    p, cfg, x, t, cond, ref = text_cond_reference
     fp8 = mode.endswith('+fp8attn')
     mode = mode.split('+')[0]
     m = Unet3D(rngs=0, mode=mode, dim=64, channels=1, use_bert_text_cond=True, attn_fp8=fp8)
     assert m.cond_dim == 768 and m.has_cond
     m.load_state_dict({k: v.float() for k, v in p.items()})
-    g = torch.Generator().manual_seed(6)
-    x = torch.randn(1, 1, 16, 64, 64, generator=g)
-    t = torch.tensor([640])
-    cond = torch.randn(1, 768, generator=g)
     y = m.forward_with_cond_scale(x, t, cond=cond, cond_scale=2.0)
-    ref = R.forward_with_cond_scale(p, cfg, x.double(), t, cond=cond.double(), cond_scale=2.0)
     r = _rel(y.cpu().double(), ref)
     print(f'cond 768 CFG {mode}{"+fp8attn" if fp8 else ""}: rel-L2 {r:.3e}')
     assert r < tol, r

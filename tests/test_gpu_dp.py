@@ -273,4 +273,6 @@ def test_abi_communicator_one_rank_train_step():
                 assert vdx_allreduce_bucket(h.ptr, L.ptr(m.flat_params), 16, L.stream_ptr()) != 0       # no communicator: loud, not silent
     finally:
         Trainer.comm_backend, Trainer.min_bucket_floats = keep
-    assert torch.equal(res['torch'][0], res['abi'][0]) and res['torch'][1] == res['abi'][1]
+    # (weight gradients accumulate with fp32 atomics: two runs of the SAME step agree to rounding, not bitwise)
+    d = (res['torch'][0] - res['abi'][0]).double().norm() / res['torch'][0].double().norm()
+    assert d < 1e-5 and abs(res['torch'][1] - res['abi'][1]) < 1e-5, (d, res['torch'][1], res['abi'][1])

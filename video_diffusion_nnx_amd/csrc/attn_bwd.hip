@@ -239,13 +239,15 @@ __global__ __launch_bounds__(512, 2) void attn_bwd16x_kernel(AttnBwdXArgs P) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
+            uint4 x16 = make_uint4(0u, 0u, 0u, 0u);
             if (tvalid) {
-                const float* xp = P.x + prow * 64 + ks * 32 + 8 * q;
-                const float* gp = P.g + prow * 64 + ks * 32 + 8 * q;
-                a = *reinterpret_cast<const float4*>(xp); b = *reinterpret_cast<const float4*>(xp + 4);
+                const size_t xe = prow * 64 + ks * 32 + 8 * q;
+                const float* gp = P.g + xe;
+                if (P.x_bf16) x16 = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.x) + xe * 2);      // bf16 activation storage: the fragment as it is
+                else { a = *reinterpret_cast<const float4*>(P.x + xe); b = *reinterpret_cast<const float4*>(P.x + xe + 4); }
                 c = *reinterpret_cast<const float4*>(gp); d = *reinterpret_cast<const float4*>(gp + 4);
             }
-            xf[ks] = pack8u_bf16(a, b); gf[ks] = pack8u_bf16(c, d);
+            xf[ks] = P.x_bf16 ? x16 : pack8u_bf16(a, b); gf[ks] = pack8u_bf16(c, d);
         }
         f32x4 dxT[4] = {z, z, z, z};                                   // dx^T: rows = channels 16 ct + 4q + e, column = token lp
 #pragma unroll 1

@@ -33,7 +33,8 @@ struct Model {
     vdx_config cfg;
     int mode, init_dim, out_dim, time_dim, temb_dim;
     int attn_fp8 = 0;                    // bf16 mode only: QK^T / PV of the <= 16-token attention cores on fp8 operands (forward only)
-    int act16 = 0;                       // bf16 mode only: store every inter-kernel activation as bf16 (inference; the backward reads fp32 slots)
+    int act16 = 0;                       // bf16 mode only: store every inter-kernel activation as bf16.  1 = inference (every fusion on); 2 = training forward
+                                         // (every slot vdx_unet_backward reads is materialised: the 1x1 res_conv output is not folded into the block tail)
     std::vector<ParamInfo> params; long param_total = 0;
     size_t packed_bytes = 0;
     size_t packed_t_bytes = 0;

@@ -374,7 +374,8 @@ static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, 
     if (e != hipSuccess) return e;
     const float* rsrc = x0;
     // bf16 activation storage: the 1x1 res_conv runs inside the tail (resblock_tail_rc16_kernel) for the shapes it is built for
-    const bool fuse_rc = r.has_res && f.a16 && m->mode == MODE_BF16 &&
+    // (act16 == 2, the training forward: r = res_conv(x) must exist in its slot, the backward's LayerNorm branch reads it)
+    const bool fuse_rc = r.has_res && f.a16 && m->act16 == 1 && m->mode == MODE_BF16 &&
                          tail_rc16_supported(c0 + c1, c0, r.cout, (long)m->cfg.num_frames * S * S);
     if (r.has_res && !fuse_rc) {
         ConvArgs c;

@@ -19,6 +19,7 @@ constexpr int LVL_BUFS = 7;
 
 struct Bwd {
     const Model* m; const float* p; const char* pk; const char* pt; float* grads; int B; hipStream_t st;
+    int a16 = 0;                                    // the forward stored its inter-kernel activations as bf16 (Model::act16 == 2): every slot read here is a bf16 tensor
     // forward workspace views
     float* act; float* temb; float* ss; float* ss_lin; double* stats;
     // backward workspace views
@@ -99,6 +100,7 @@ void wgrad(Bwd& b, const float* x0, int c0, const float* x1, int c1, const float
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.dy_bf16 = dy_bf16;
+    a.x0_bf16 = b.a16;                                             // x0 / x1 are forward slots (block inputs); y1 (prologue form) is bf16 in bf16 mode either way
     a.x0 = x0; a.x1 = x1; a.C0 = c0; a.C1 = c1; a.dy = dy; a.Cout = Cout; a.dW = b.grads + w_off; a.db = b_off >= 0 ? b.grads + b_off : nullptr;
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl_in);
     a.kind = kind; a.kh = a.kw = kind ? 4 : k; a.stride = kind ? 1 : stride;
@@ -122,7 +124,7 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     const int d16 = (m->mode == MODE_BF16) ? 1 : 0;      // bf16 mode: dL/d(y2), dL/d(y1) are bf16 tensors (only convolutions read them)
     t.dact = g; t.y = b.slot(r.s_y2); t.y_bf16 = (m->mode == MODE_BF16); t.dy = L.t1; t.dy_bf16 = d16; t.stats = b.stat(r.st2); t.gamma = b.p + r.b2_gs; t.beta = b.p + r.b2_gb; t.groups = G;
     t.d_gamma = b.grads + r.b2_gs; t.d_beta = b.grads + r.b2_gb;
-    t.r = rsrc; t.ln_gamma = b.p + r.n2_s; t.dr = L.t2; t.d_ln_gamma = b.grads + r.n2_s; t.d_ln_beta = b.grads + r.n2_b;
+    t.r = rsrc; t.r_bf16 = b.a16; t.ln_gamma = b.p + r.n2_s; t.dr = L.t2; t.d_ln_gamma = b.grads + r.n2_s; t.d_ln_beta = b.grads + r.n2_b;
     // R at a fixed offset of the scratch: zeroed once per backward, the finalize pass leaves it zero again
     t.G = b.normscr; t.R = b.normscr + (size_t)b.B * 64; t.C = r.cout; t.batch = b.B; t.pix_per_sample = b.pix(lvl);
     b.ok(launch_norm_bwd(t, b.writes(L.t1, L.t2)));
@@ -179,10 +181,10 @@ void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w
 }
 
 // the q, k and v projection weight gradients of one block in ONE launch: dy = [rows][dq | dk | dv], x read once
-void wgrad1x1_qkv(Bwd& b, const float* x, int cin, const float* dqkv, int hd, const long (&w_off)[3], const long* b_off, int lvl, int dy_bf16 = 0) {
+void wgrad1x1_qkv(Bwd& b, const float* x, int cin, const float* dqkv, int hd, const long (&w_off)[3], const long* b_off, int lvl, int dy_bf16 = 0, int x_bf16 = 0) {
     WgradArgs a;
     memset(&a, 0, sizeof(a));
-    a.dy_bf16 = dy_bf16;
+    a.dy_bf16 = dy_bf16; a.x0_bf16 = x_bf16;
     a.x0 = x; a.C0 = cin; a.dy = dqkv; a.Cout = 3 * hd; a.split = hd;
     a.dW = b.grads + w_off[0]; a.dW1 = b.grads + w_off[1]; a.dW2 = b.grads + w_off[2];
     if (b_off) { a.db = b.grads + b_off[0]; a.db1 = b.grads + b_off[1]; a.db2 = b.grads + b_off[2]; }
@@ -208,16 +210,16 @@ void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, 
         // widest level: one fused kernel (attn_bwd16x_kernel) instead of recompute / dO projection / core / dx projection
         AttnBwdXArgs f;
         memset(&f, 0, sizeof(f));
-        f.x = x; f.g = g; f.wqkv = b.pk + ap.pk_qkv; f.bqkv = reinterpret_cast<const float*>(b.pk + ap.pk_bqkv); f.woT = b.pt + ap.pt_o;
+        f.x = x; f.x_bf16 = b.a16; f.g = g; f.wqkv = b.pk + ap.pk_qkv; f.bqkv = reinterpret_cast<const float*>(b.pk + ap.pk_bqkv); f.woT = b.pt + ap.pt_o;
         f.O = O; f.dqkv = dq; f.dx = out; f.L = (int)Fr; f.nseq = b.B * hw; f.inner = hw; f.outer_p = Fr * hw; f.tok_p = hw;
         f.scale = 1.0f / sqrtf((float)m->cfg.attn_dim_head);
         b.writes(out);
         b.ok(launch_attn_bwd_fused(f, b.st));
         wgrad1x1(b, O, HD, g, C, ap.o_w, ap.o_b, lvl, 1);
-        wgrad1x1_qkv(b, x, C, dq, HD, ap.w, ap.b, lvl, 1);
+        wgrad1x1_qkv(b, x, C, dq, HD, ap.w, ap.b, lvl, 1, b.a16);
         return;
     }
-    proj(b, x, C, b.pk + ap.pk_qkv, reinterpret_cast<const float*>(b.pk + ap.pk_bqkv), 3 * HD, lvl, nullptr, qkv, 0, io16);
+    proj(b, x, C, b.pk + ap.pk_qkv, reinterpret_cast<const float*>(b.pk + ap.pk_bqkv), 3 * HD, lvl, nullptr, qkv, b.a16, io16);
     proj(b, g, C, b.pt + ap.pt_o, nullptr, HD, lvl, nullptr, dO, 0, io16);                           // dO = g . Wo^T
     AttnBwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -230,7 +232,7 @@ void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, 
     a.bf16_mma = (m->mode == MODE_BF16);
     b.ok(launch_attn_core_bwd(a, b.writes(b.S)));
     wgrad1x1(b, O, HD, g, C, ap.o_w, ap.o_b, lvl, io16);
-    wgrad1x1_qkv(b, x, C, dq, HD, ap.w, ap.b, lvl, io16);
+    wgrad1x1_qkv(b, x, C, dq, HD, ap.w, ap.b, lvl, io16, b.a16);
     proj(b, dq, 3 * HD, b.pt + ap.pt_qkv, nullptr, C, lvl, g, out, io16, 0);                          // dx = g + [dq|dk|dv] . [Wq;Wk;Wv]^T
 }
 
@@ -242,9 +244,9 @@ void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, fl
     float* dq = O + npix * HD;      // [npix][dq | dk | dv]
     const int io16 = (m->mode == MODE_BF16) ? 1 : 0;      // bf16 mode: q, k, v, dOut, O and dq|dk|dv are bf16 tensors in fp32-sized scratch places
     b.writes(b.S);
-    proj(b, x, C, b.pk + sp.pk[0], nullptr, HD, lvl, nullptr, q, 0, io16);
-    proj(b, x, C, b.pk + sp.pk[1], nullptr, HD, lvl, nullptr, k, 0, io16);
-    proj(b, x, C, b.pk + sp.pk[2], nullptr, HD, lvl, nullptr, v, 0, io16);
+    proj(b, x, C, b.pk + sp.pk[0], nullptr, HD, lvl, nullptr, q, b.a16, io16);
+    proj(b, x, C, b.pk + sp.pk[1], nullptr, HD, lvl, nullptr, k, b.a16, io16);
+    proj(b, x, C, b.pk + sp.pk[2], nullptr, HD, lvl, nullptr, v, b.a16, io16);
     proj(b, g, C, b.pt + sp.pt_o, nullptr, HD, lvl, nullptr, dOut, 0, io16);
     SlaBwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -255,7 +257,7 @@ void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, fl
     a.bf16_mma = (m->mode == MODE_BF16);
     b.ok(launch_sla_bwd(a, b.writes(b.S)));
     wgrad1x1(b, O, HD, g, C, sp.o_w, -1, lvl, io16);
-    wgrad1x1_qkv(b, x, C, dq, HD, sp.w, nullptr, lvl, io16);
+    wgrad1x1_qkv(b, x, C, dq, HD, sp.w, nullptr, lvl, io16, b.a16);
     proj(b, dq, 3 * HD, b.pt + sp.pt_qkv, nullptr, C, lvl, g, out, io16, 0);
 }
 
@@ -328,6 +330,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
     Bwd b;
     b.m = m; b.p = params; b.pk = reinterpret_cast<const char*>(packed); b.pt = reinterpret_cast<const char*>(packed_t);
     b.grads = grads; b.B = B; b.st = st; b.state = state;
+    b.a16 = (m->act16 == 2 && m->mode == MODE_BF16) ? 1 : 0;
     {   // forward workspace carve (must match model_forward)
         char* w = reinterpret_cast<char*>(fwd_workspace);
         b.act = reinterpret_cast<float*>(w); w += ((size_t)m->act_floats_per_sample * B * 4 + 255) / 256 * 256;
@@ -369,7 +372,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             VDX_E(hipMemsetAsync(b.dtemb, 0, (size_t)m->temb_dim * B * 4, st));
             // head: out = conv1x1(fin(concat(x_up, r)))
             const Level& U = m->ups[nl - 1];
-            VDX_E(launch_final_conv_bwd(b.slot(m->fin.s_out), d_out, params + m->fin_w, b.lv[0].ga, grads + m->fin_w, grads + m->fin_b, pix0, c.dim, m->out_dim, b.writes(b.lv[0].ga)));
+            VDX_E(launch_final_conv_bwd(b.slot(m->fin.s_out), d_out, params + m->fin_w, b.lv[0].ga, grads + m->fin_w, grads + m->fin_b, pix0, c.dim, m->out_dim, b.a16, b.writes(b.lv[0].ga)));
             res_bwd(b, m->fin, b.lv[0].ga, b.slot(U.s_attn), U.cout, b.slot(m->s_init_attn), m->init_dim, 0, b.lv[0].gb, b.gr);
             g = b.lv[0].gb;
         } else if (stage >= nl + 2) {

@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs P) {
             for (int v = 0; v < VPL; ++v) {
                 const int c = (v * LPP + sub) * 4;
                 const size_t e = base + (c < C ? c : 0);
-                rr[u][v] = P.r ? *reinterpret_cast<const float4*>(P.r + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+                rr[u][v] = P.r ? load4_f32_or_bf16(P.r, e, P.r_bf16) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (P.y_bf16) {
                     const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.y) + e * 2);
                     yv4[u][v] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), 0.f, 0.f);      // raw, widened below
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs P) {
             for (int v = 0; v < VPL; ++v) {
                 const int c = (v * LPP + sub) * 4;
                 if (c < C) {
-                    rr[v] = *reinterpret_cast<const float4*>(P.r + base + c);
+                    rr[v] = load4_f32_or_bf16(P.r, base + c, P.r_bf16);
                     s += rr[v].x + rr[v].y + rr[v].z + rr[v].w;
                     ss += rr[v].x * rr[v].x + rr[v].y * rr[v].y + rr[v].z * rr[v].z + rr[v].w * rr[v].w;
                 }

@@ -24,13 +24,13 @@ __global__ __launch_bounds__(256) void final_conv_dx_kernel(const float* __restr
 
 // final conv: dW[c][co] += sum_pix x[pix][c] dout[pix][co] ; db[co] += sum_pix dout[pix][co]     (D <= 256, Cout <= 4)
 __global__ __launch_bounds__(256) void final_conv_dw_kernel(const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dW,
-                                                            float* __restrict__ db, long npix, int D, int Cout) {
+                                                            float* __restrict__ db, long npix, int D, int Cout, int x_bf16) {
     __shared__ float red[256 * 4];
     const int c = threadIdx.x % D, pl = threadIdx.x / D, PL = 256 / D;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
     if (pl < PL)
         for (long pix = (long)blockIdx.x * PL + pl; pix < npix; pix += (long)gridDim.x * PL) {
-            const float xv = x[pix * D + c];
+            const float xv = x_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(x)[pix * D + c] << 16) : x[pix * D + c];
             for (int co = 0; co < Cout; ++co) { const float d = dout[pix * Cout + co]; acc[co] = fmaf(xv, d, acc[co]); accb[co] += d; }
         }
     for (int co = 0; co < Cout; ++co) {
@@ -247,13 +247,13 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(TimeMlpArgs P, const 
         }
 }
 
-hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, hipStream_t st) {
+hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, int x_bf16, hipStream_t st) {
     if (D > 256 || Cout > 4) return hipErrorInvalidValue;
     const int blocks = (int)std::max<long>(1, std::min<long>((npix * (D / 4) + 255) / 256, 4096));
     hipLaunchKernelGGL(final_conv_dx_kernel, dim3(blocks), dim3(256), 0, st, dout, w, dx, npix, D, Cout);
     const int PL = 256 / D;
     const int b2 = (int)std::max<long>(1, std::min<long>((npix + PL - 1) / PL, 512));
-    hipLaunchKernelGGL(final_conv_dw_kernel, dim3(b2), dim3(256), 0, st, x, dout, dW, db, npix, D, Cout);
+    hipLaunchKernelGGL(final_conv_dw_kernel, dim3(b2), dim3(256), 0, st, x, dout, dW, db, npix, D, Cout, x_bf16);
     return hipGetLastError();
 }
 

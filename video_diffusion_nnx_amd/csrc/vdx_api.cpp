@@ -282,7 +282,8 @@ void vdx_destroy(vdx_handle* h) {
 int vdx_set_activation_storage(vdx_handle* h, int bf16) {
     if (!h) VDX_FAIL(VDX_ERR_INVALID, "set_activation_storage: null handle");
     if (bf16 && h->model.mode != VDX_MODE_BF16) VDX_FAIL(VDX_ERR_INVALID, "bf16 activation storage needs a VDX_MODE_BF16 handle");
-    const int v = bf16 ? 1 : 0;
+    if (bf16 < 0 || bf16 > 2) VDX_FAIL(VDX_ERR_INVALID, "set_activation_storage: 0 (fp32), 1 (bf16, inference) or 2 (bf16, training forward)");
+    const int v = bf16;
     if (v != h->model.act16) {                       // a cached sampling graph was captured with the other storage
         h->drop_graphs();
         h->model.act16 = v;
@@ -612,7 +613,7 @@ int vdx_unet_backward(vdx_handle* h, const float* params, const void* packed, co
                       void* bwd_workspace, size_t bwd_workspace_bytes, float* grads, int stage_hi, int stage_lo, int batch, void* stream) {
     if (!h || !params || !packed || !packed_t || !x || !time || !d_out || !fwd_workspace || !bwd_workspace || !grads) VDX_FAIL(VDX_ERR_INVALID, "unet_backward: null argument");
     if (!h->model.d_ss_layers) VDX_FAIL(VDX_ERR_STATE, "unet_backward: handle was created without a GPU");
-    if (h->model.act16) VDX_FAIL(VDX_ERR_STATE, "unet_backward: the forward ran with bf16 activation storage; the backward reads fp32 slots");
+    if (h->model.act16 == 1) VDX_FAIL(VDX_ERR_STATE, "unet_backward: the forward ran with the INFERENCE form of bf16 activation storage (res_conv folded into the block tail); use vdx_set_activation_storage(h, 2) for a forward that feeds the backward");
     if (h->model.attn_fp8) VDX_FAIL(VDX_ERR_STATE, "unet_backward: fp8 attention is a forward (sampling) option; the backward differentiates the bf16 cores");
     // the fused q|k|v weight gradient (wgrad.hip, split = heads * 32) owns whole 64-wide output tiles per tensor
     if ((h->model.cfg.attn_heads * 32) % 64) VDX_FAIL(VDX_ERR_INVALID, "unet_backward: attn_heads must be even (heads * 32 a multiple of 64); odd head counts are forward / sampling only");

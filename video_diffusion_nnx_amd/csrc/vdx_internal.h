@@ -172,7 +172,7 @@ struct WgradArgs {
     int NF, F, H, W;                                       // input geometry
     int kind, kh, kw, stride;
     int pro; const double* in_stats; const float* gamma; const float* beta; int groups; const float* ss; int ss_stride;
-    int x0_bf16;                                           // x0 stored as bf16
+    int x0_bf16;                                           // x0 (and x1) stored as bf16
     int dy_bf16;                                           // dy stored as bf16 (backward intermediates of bf16 mode)
     int split; float* dW1; float* dW2; float* db1; float* db2;   // split > 0: dY column block co / split goes to (dW, dW1, dW2)[co / split], each [taps][Cin][split]
     int bf16_mma;                                          // bf16 MFMA operands (bf16 mode) instead of exact f32
@@ -192,6 +192,7 @@ struct NormBwdArgs {
     const float* dact; const float* y; float* dy;                 // dL/dact (or dL/dout), saved pre-norm tensor, result dL/dy
     int y_bf16;                                                   // y stored as bf16
     int dy_bf16;                                                  // dy written as bf16 (its consumers, the conv data / weight gradients, round it to bf16 anyway)
+    int r_bf16;                                                   // r stored as bf16 (bf16 activation storage of the training forward)
     const double* stats; const float* gamma; const float* beta; int groups;
     const float* ss; int ss_stride;                               // forward scale/shift rows or null
     float* d_gamma; float* d_beta;                                // accumulated (atomics)
@@ -218,6 +219,7 @@ hipError_t launch_attn_core_bwd(const AttnBwdArgs& a, hipStream_t st);
 // core and dx = g + dq|dk|dv . Wqkv^T in one kernel; O and dq|dk|dv are written (bf16) for the weight-gradient kernels
 struct AttnBwdXArgs {
     const float* x; const float* g;            // block input, dL/d(block output): fp32 [rows][64]
+    int x_bf16;                                // x stored as bf16 (bf16 activation storage of the training forward)
     const void* wqkv; const float* bqkv;       // forward packing [3 * 256][64] bf16, biases [3 * 256]
     const void* woT;                           // transposed packing of the out-projection [256][64] bf16
     void* O; void* dqkv;                       // bf16 [rows][256], [rows][768]
@@ -236,7 +238,7 @@ struct SlaBwdArgs {
 size_t sla_bwd_scratch_floats(int NF, int heads);
 hipError_t launch_sla_bwd(const SlaBwdArgs& a, hipStream_t st);
 
-hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, hipStream_t st);
+hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, int x_bf16, hipStream_t st);
 hipError_t launch_init_conv_wgrad(const float* x, const float* dy, float* dW, float* db, int B, int Cin, int F, int H, int W, int Cout, int K, hipStream_t st);
 hipError_t launch_resblock_ss_bwd(const float* params, float* grads, const float* temb, const SsLayer* layers, int nlayers, const float* lin_base,
                                   float* dss_base, float* dtemb, int temb_dim, int B, hipStream_t st);

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
             if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin) {
                 const size_t pix = ((size_t)f * P.H + gy) * P.W + gx;
                 v = (c < P.C0) ? load4_f32_or_bf16(P.x0, pix * P.C0 + c, P.x0_bf16)
-                               : *reinterpret_cast<const float4*>(P.x1 + pix * P.C1 + (c - P.C0));
+                               : load4_f32_or_bf16(P.x1, pix * P.C1 + (c - P.C0), P.x0_bf16);
                 if (P.pro) {
                     const float4 a = *reinterpret_cast<const float4*>(coefA + pc * 4);
                     const float4 d = *reinterpret_cast<const float4*>(coefD + pc * 4);
@@ -263,7 +263,9 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel
             const bool ok = i < HPX * 16 && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin;
             const size_t pix = ok ? ((size_t)f * P.H + gy) * P.W + gx : 0;
             if (X16) {
-                const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(P.x0) + (ok ? (pix * P.C0 + c) * 2 : 0));
+                const char* src = (!ok || c < P.C0) ? reinterpret_cast<const char*>(P.x0) + (ok ? (pix * P.C0 + c) * 2 : 0)
+                                                    : reinterpret_cast<const char*>(P.x1) + (pix * P.C1 + (c - P.C0)) * 2;
+                const uint2 t = *reinterpret_cast<const uint2*>(src);
                 ra[u] = make_float4(__uint_as_float(t.x), __uint_as_float(t.y), 0.f, 0.f);
             } else {
                 const float* src = (!ok || c < P.C0) ? P.x0 + (ok ? pix * P.C0 + c : 0) : P.x1 + pix * P.C1 + (c - P.C0);
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel
                 if (gy >= 0 && gy < P.H && gx >= 0 && gx < P.W && c < Cin) {
                     const size_t pix = ((size_t)f * P.H + gy) * P.W + gx;
                     v = (c < P.C0) ? load4_f32_or_bf16(P.x0, pix * P.C0 + c, P.x0_bf16)
-                                   : *reinterpret_cast<const float4*>(P.x1 + pix * P.C1 + (c - P.C0));
+                                   : load4_f32_or_bf16(P.x1, pix * P.C1 + (c - P.C0), P.x0_bf16);
                     if (P.pro) {
                         const float4 a = *reinterpret_cast<const float4*>(coefA + pc * 4);
                         const float4 d = *reinterpret_cast<const float4*>(coefD + pc * 4);
@@ -489,14 +491,14 @@ __global__ __launch_bounds__(256, NCO == 4 ? 2 : 4) void wgrad1x1_kernel(const W
         const long row0 = t * 64;
         const int left = (int)min((long)64, rows - row0);         // rows of this tile (uniform)
         const char* xb0 = reinterpret_cast<const char*>(P.x0) + (size_t)row0 * P.C0 * (X16 ? 2 : 4);
-        const char* xb1 = reinterpret_cast<const char*>(P.x1) + (size_t)row0 * P.C1 * 4;
+        const char* xb1 = reinterpret_cast<const char*>(P.x1) + (size_t)row0 * P.C1 * (X16 ? 2 : 4);
         const char* yb = reinterpret_cast<const char*>(P.dy) + (size_t)row0 * P.Cout * (DY16 ? 2 : 4);
         va = 0; vb = 0;
 #pragma unroll
         for (int u = 0; u < XA; ++u) {
             const bool ok = ((tid + u * 256) >> 4) < left && ((cokA >> u) & 1u);
             const size_t o = ok ? (size_t)offA[u] : 0;
-            if constexpr (X16) ra[u] = *reinterpret_cast<const uint2*>(xb0 + o * 2);
+            if constexpr (X16) ra[u] = *reinterpret_cast<const uint2*>((ok && ((isx1 >> u) & 1u) ? xb1 : xb0) + o * 2);
             else ra[u] = *reinterpret_cast<const float4*>((ok && ((isx1 >> u) & 1u) ? xb1 : xb0) + o * 4);
             va |= (ok ? 1u : 0u) << u;
         }
@@ -687,7 +689,6 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
             const long nth = NT == 1 ? 256 : 512;
             if ((long)IH * IW * 16 > 6 * nth || (long)a.PH * a.sb * a.PW * a.sb * 16 > 4 * nth) return hipErrorInvalidValue;
         }
-        if (a.x0_bf16 && a.C1) return hipErrorInvalidValue;      // the bf16 x0 form has no concat operand
         // projections: the split-K GEMM form (wide output tiles when Cout allows: x is staged Cout / 256 times instead of Cout / 64)
         const int use_1x1 = 2;   // 0: patch kernel, 1: GEMM form for wide outputs only, 2: always
         if (use_1x1 && NT == 1 && a.kind == 0 && a.stride == 1 && !a.pro && (a.Cout % 256 == 0 || use_1x1 == 2)) {

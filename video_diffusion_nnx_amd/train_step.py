@@ -55,7 +55,12 @@ def run_train_step(tr, batch: torch.Tensor, step: int, t: torch.Tensor = None, n
     noise = gd.randn(x.shape, noise_key, 0) if noise is None else torch.as_tensor(noise).to(dev, torch.float32).contiguous()
     tr.last_t, tr.last_noise_key = t, noise_key
     x_noisy = gd.q_sample(x, t, noise=noise, _pre=(2.0, -1.0))                    # normalize_img folded in (:499)
-    eps_hat = unet(x_noisy, t)
+    keep_storage = unet.act_bf16
+    unet.act_bf16 = 2 if (unet.mode == 'bf16' and tr.train_act_bf16) else False
+    try:
+        eps_hat = unet(x_noisy, t)
+    finally:
+        unet.act_bf16 = keep_storage
     acc = torch.zeros(1, dtype=torch.float64, device=dev)
     fhw = x.numel() // (B * gd.channels)
     l2 = int(gd.loss_type == 'l2')

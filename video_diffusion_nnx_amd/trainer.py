@@ -124,6 +124,9 @@ class Trainer:
     # 'torch': torch.distributed.all_reduce per bucket (RCCL under the nccl backend; gloo in the CPU / one-GPU tests).
     # 'abi': the communicator inside libvdx.so (vdx_comm_init / vdx_allreduce_bucket); needs a CUDA device.  VDX_COMM overrides.
     comm_backend = os.environ.get('VDX_COMM', 'torch')
+    # mode='bf16' networks: the training forward stores its inter-kernel activations as bf16 (vdx_set_activation_storage(h, 2)) -- the
+    # forward then runs on the sampling path's kernels and every activation read of the backward halves; False = fp32 slots
+    train_act_bf16 = True
     # gradient all-reduce bucket size (floats): >= 16 MB per RCCL call keeps every xGMI ring step bandwidth-bound; the
     # constructor signature stays the reference's, so this is a class attribute
     min_bucket_floats = 4 << 20

@@ -140,8 +140,9 @@ class Unet3D:
         self.resnet_groups = resnet_groups
         self.mode = mode
         self.mode_id = L.MODES[mode]
-        # bf16 mode only: store every inter-kernel activation as bf16 (inference).  GaussianDiffusion turns it on for its
-        # sampling loops; forwards that feed backward() need it off (the backward reads the fp32 slots).
+        # bf16 mode only: store every inter-kernel activation as bf16.  True / 1: inference (GaussianDiffusion turns it on for its
+        # sampling loops; every fusion on, backward() refuses such a forward); 2: the training forward (every slot the backward reads
+        # is materialised as a bf16 tensor -- what Trainer uses); False: fp32 slots (inspectable with slot(), the parity default).
         self.act_bf16 = False
         if attn_fp8 and mode != 'bf16':
             raise ValueError("attn_fp8 needs mode='bf16'")
@@ -311,7 +312,7 @@ class Unet3D:
     def apply_activation_storage(self, h) -> None:
         if self.act_bf16 and self.mode != 'bf16':
             raise ValueError("act_bf16 needs mode='bf16'")
-        L.check(vdx_set_activation_storage(h.ptr, int(bool(self.act_bf16))))
+        L.check(vdx_set_activation_storage(h.ptr, 2 if self.act_bf16 == 2 and self.act_bf16 is not True else int(bool(self.act_bf16))))
         L.check(vdx_set_attention_fp8(h.ptr, int(self.attn_fp8)))
 
     def workspace(self, batch: int, frames: int, size: int) -> torch.Tensor:
