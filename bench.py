@@ -211,7 +211,7 @@ def train_leg(args, dev, world, rank):
     n_buckets = len(tr.buckets)
     return {'samples_per_s': world * B / (ms * 1e-3), 'ms_per_step': ms, 'batch_per_gpu': B, 'global_batch': B * world,
             'allreduce_exposed_ms': exposed, 'comm': args.comm, 'grad_bytes': int(unet.flat_params.numel()) * 4, 'buckets': n_buckets,
-            'what': 'q_sample + Unet3D fwd (fp32 activation storage) + l2 loss + staged backward + bucketed sum all-reduce + Adam + EMA'}
+            'what': 'q_sample + Unet3D fwd (bf16 activation storage kept for the backward in bf16 mode) + l2 loss + staged backward + bucketed sum all-reduce + Adam + EMA'}
 
 
 def sampling_leg(args, dev, world, rank, dim, Fr, S, B, steps, warmup, roofline):
@@ -262,7 +262,8 @@ def sampling_leg(args, dev, world, rank, dim, Fr, S, B, steps, warmup, roofline)
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = tt.item()
-    assert torch.isfinite(img).all(), 'sampling produced non-finite values'
+    if not os.environ.get('VDX_BENCH_DIAG'):          # (tools/ab_step.sh with knock-out variants of a kernel: results are garbage by construction)
+        assert torch.isfinite(img).all(), 'sampling produced non-finite values'
     del img, eps, ws
     unet._ws.clear()
     torch.cuda.empty_cache()

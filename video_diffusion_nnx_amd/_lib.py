@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvdx.so')
+# VDX_LIB: a variant build of the same sources (tools/ab_variants.sh: A/B timing of kernel changes); the product path is the in-tree library
+LIB_PATH = os.environ.get('VDX_LIB') or os.path.join(_HERE, 'libvdx.so')
 
 MODE_F32 = 0
 MODE_BF16 = 1

@@ -428,6 +428,22 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     constexpr int RSY = CT * 4 + 16;
     // one-barrier pipeline with double-buffered os / ys where the LDS allows it: bf16 operands, C <= 64 (the level-0 kernels: 123 KB)
     constexpr bool PIPE = MODE == MODE_BF16 && NKT == 1;
+    // 2-byte operands: the 32 columns of a head's block of os are stored in the order the PV accumulators hold them -- lane (token, q) owns
+    // d = 4q..4q+3 (t = 0) and 16+4q..16+4q+3 (t = 1) = K slots 8q..8q+7 of the head's chunk -- so the lane writes ONE 16-byte piece
+    // (ds_write_b128 over 8-lane groups at a 132-dword row stride: conflict-free) instead of two 8-byte pieces whose 16 rows collide two
+    // by two (39 % of the kernel's LDS cycles were those conflicts: profiles/r02_pmc_step.md).  The out-projection's weight fragments
+    // are loaded with the same permutation of K, so the product is unchanged.
+#ifndef VDX_H8_OSP
+#define VDX_H8_OSP 2
+#endif
+    constexpr bool OSP = M::ES == 2 && VDX_H8_OSP != 0 && (VDX_H8_OSP == 1 || PIPE);
+    static_assert(!OSP || MODE == MODE_BF16, "the packed os store writes bf16");
+    // phase A on SB sequences at a time, stage by stage (projections of all SB, scores, softmax, PV): SB independent dependency chains
+    // in flight instead of one (MFMA result -> cvt -> MFMA -> max -> permlane -> exp -> ... is ~30 dependent steps per sequence)
+#ifndef VDX_H8_SB
+#define VDX_H8_SB 4
+#endif
+    constexpr int SB = PIPE ? VDX_H8_SB : 1;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];      // xs[2][NKT][64][RS] | os[64][RSO] | ys[64][RSY] (fp32); PIPE: os, ys twice
     char* os = smem + 2 * BUF;
@@ -509,7 +525,13 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     for (int tmo = 0; tmo < TMO; ++tmo)
 #pragma unroll
         for (int ch = 0; ch < NCHO; ++ch)
-            wof[tmo][ch] = *reinterpret_cast<const uint4*>(wo + (size_t)((cot0 + tmo) * 16 + lp) * P.HDPad * M::ES + ch * 64 + q * 16);
+        {
+            const char* wrow = wo + (size_t)((cot0 + tmo) * 16 + lp) * P.HDPad * M::ES + ch * 64;
+            if constexpr (OSP) {
+                const uint2 lo = *reinterpret_cast<const uint2*>(wrow + q * 8), hi = *reinterpret_cast<const uint2*>(wrow + 32 + q * 8);
+                wof[tmo][ch] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            } else wof[tmo][ch] = *reinterpret_cast<const uint4*>(wrow + q * 16);
+        }
     f32x4 bo[TMO];
 #pragma unroll
     for (int tmo = 0; tmo < TMO; ++tmo) {
@@ -526,42 +548,75 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     // A: per-head attention of the 4 sequences of the x tile `xs` -> os_w[row][h*32 + d]
     auto phase_a = [&](const char* xs, char* os_w) __attribute__((always_inline)) {
 #pragma unroll
-        for (int sl = 0; sl < 4; ++sl) {               // one sequence = one 16-row tile
-            f32x4 aq[2], ak[2], av[2];
+        for (int s0 = 0; s0 < 4; s0 += SB) {           // SB sequences (16-row tiles) per batch
+            f32x4 aq[SB][2], ak[SB][2], av[SB][2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { aq[t] = bq[t]; ak[t] = bk[t]; av[t] = bv[t]; }
+            for (int b = 0; b < SB; ++b)
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt)
+                for (int t = 0; t < 2; ++t) { aq[b][t] = bq[t]; ak[b][t] = bk[t]; av[b][t] = bv[t]; }
 #pragma unroll
-                for (int ch = 0; ch < 2; ++ch) {
-                    const uint4 xf = *reinterpret_cast<const uint4*>(xs + kt * PLANE + (sl * 16 + lp) * RS + ch * 64 + q * 16);
+            for (int b = 0; b < SB; ++b)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        M::mma(aq[t], wf[kt][ch][0][t], xf);
-                        M::mma(ak[t], wf[kt][ch][1][t], xf);
-                        M::mma(av[t], xf, wf[kt][ch][2][t]);      // swapped: rows = tokens, cols = d
+                for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const uint4 xf = *reinterpret_cast<const uint4*>(xs + kt * PLANE + ((s0 + b) * 16 + lp) * RS + ch * 64 + q * 16);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            M::mma(aq[b][t], wf[kt][ch][0][t], xf);
+                            M::mma(ak[b][t], wf[kt][ch][1][t], xf);
+                            M::mma(av[b][t], xf, wf[kt][ch][2][t]);      // swapped: rows = tokens, cols = d
+                        }
                     }
-                }
-            f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};      // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
-            core_mma16<M, F8>(sc, ak[0], aq[0]);
-            core_mma16<M, F8>(sc, ak[1], aq[1]);
-            if (masked) {
+            f32x4 sc[SB];                              // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (4 * q + r >= seq_len) sc[r] = -1e30f;
+            for (int b = 0; b < SB; ++b) {
+                sc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                core_mma16<M, F8>(sc[b], ak[b][0], aq[b][0]);
+                core_mma16<M, F8>(sc[b], ak[b][1], aq[b][1]);
             }
-            const float mx = max_q(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
-            const float nmx = -mx * escale;            // exp2((s - max) * k) = exp2(fma(s, k, -max * k)): one FMA per score
-            float sum = 0.f;
+            float mx[SB], sum[SB];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], escale, nmx)); sum += sc[r]; }
-            const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
+            for (int b = 0; b < SB; ++b) {
+                if (masked) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[r] *= inv;
+                    for (int r = 0; r < 4; ++r) if (4 * q + r >= seq_len) sc[b][r] = -1e30f;
+                }
+                mx[b] = fmaxf(fmaxf(sc[b][0], sc[b][1]), fmaxf(sc[b][2], sc[b][3]));
+            }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {              // O^T[d, i] -> os[row i][h*32 + d]
-                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-                core_mma16<M, F8>(o, av[t], sc);
-                M::store4(os_w + (sl * 16 + lp) * RSO, h * D + t * 16 + 4 * q, make_float4(o[0], o[1], o[2], o[3]));
+            for (int b = 0; b < SB; ++b) mx[b] = max_q(mx[b]);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                const float nmx = -mx[b] * escale;     // exp2((s - max) * k) = exp2(fma(s, k, -max * k)): one FMA per score
+                sum[b] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[b][r] = __builtin_amdgcn_exp2f(fmaf(sc[b][r], escale, nmx)); sum[b] += sc[b][r]; }
+            }
+#pragma unroll
+            for (int b = 0; b < SB; ++b) sum[b] = reduce_q(sum[b]);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                const float inv = __builtin_amdgcn_rcpf(sum[b]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[b][r] *= inv;
+            }
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {             // O^T[d, i] -> os[row i][h*32 + d]
+                f32x4 o[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    core_mma16<M, F8>(o[t], av[b][t], sc[b]);
+                }
+                char* orow = os_w + ((s0 + b) * 16 + lp) * RSO;
+                if constexpr (OSP) {
+                    *reinterpret_cast<uint4*>(orow + h * D * 2 + q * 16) =
+                        make_uint4(pack_bf16x2(o[0][0], o[0][1]), pack_bf16x2(o[0][2], o[0][3]), pack_bf16x2(o[1][0], o[1][1]), pack_bf16x2(o[1][2], o[1][3]));
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) M::store4(orow, h * D + t * 16 + 4 * q, make_float4(o[t][0], o[t][1], o[t][2], o[t][3]));
+                }
             }
         }
     };

@@ -414,6 +414,8 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     float* coefD = coefA + 64;
     float* gmean = coefD + 64;                        // [32][mean, rstd]
     double* chs = reinterpret_cast<double*>(gmean + 64);   // [2][64] channel sum / sumsq of the current sample (f64: order-independent)
+    float* biasl = reinterpret_cast<float*>(chs + 128);    // [64] bias: read per tile in the epilogue (16 registers less to hold across the tap loop:
+                                                           // the prologue form sat on the 256-register limit and spilled)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -423,12 +425,15 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     if (t0 >= t1) return;
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x0), 0, P.x0_bytes, 0x00020000);
+    // output through a buffer descriptor too: 32-bit offsets instead of a 64-bit address per store (launcher: the tensor is < 4 GB)
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, (unsigned)P.NF * P.H * P.W * 64u * (OUT16 ? 2u : 4u), 0x00020000);
     for (int i = tid; i < 9 * 64 * 8; i += 512) {     // packed [tap][wrows][64 ci] bf16: 128-byte rows; this conv's 64 rows start at wrow0
         const int row = i >> 3, c = i & 7;            // (a slice of a wider packing: the data gradient of one half of a concat input)
         const size_t srow = (size_t)(row >> 6) * P.wrows + P.wrow0 + (row & 63);
         *reinterpret_cast<uint4*>(Wl + swz(row, c)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) + srow * 128 + c * 16);
     }
     if (tid < 128) chs[tid] = 0.0;
+    if (tid < 64) biasl[tid] = P.bias ? P.bias[tid] : 0.f;
 
     // per-thread staging pieces (constant over tiles): halo position, channel piece, LDS byte offset
     // (register budget: 256 at 2 waves per SIMD and the prologue forms sit on it -- the halo row / column share one register, the
@@ -464,7 +469,8 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             if (u < u0 || u >= u1) continue;
-            if ((pyx[u] >> 5) > 17) continue;
+            if (wave_u * 64 + 512 * u >= NPIECE) continue;               // wave-uniform: the last round of pieces (2592 = 5 x 512 + 32) is wave 0's only --
+            if ((pyx[u] >> 5) > 17) continue;                            // a per-lane test alone still issues its SiLU block in all 8 waves
             const bool ok = (okmask >> u) & 1u;
             if (IN16) {
                 u32x4 v = sreg[u];
@@ -543,9 +549,6 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     // fragment addressing: wave owns output rows py = 2 * wave + tn of the tile, pixel px = lp
     int hpb[2];
     hpb[0] = (2 * wave) * 18 + lp; hpb[1] = hpb[0] + 18;
-    float4 bias4[4];
-#pragma unroll
-    for (int tm = 0; tm < 4; ++tm) bias4[tm] = P.bias ? *reinterpret_cast<const float4*>(P.bias + tm * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 
     int fcur, tyc, txc;
     decode(t0, fcur, tyc, txc);
@@ -616,14 +619,18 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
         // ---- epilogue of tile t ----
         {
             const int oy0 = tyc * 16 + 2 * wave, ox = txc * 16 + lp;
+            float4 bias4[4];
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) bias4[tm] = *reinterpret_cast<const float4*>(biasl + tm * 16 + 4 * q);
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
-                const size_t gout = ((size_t)(fcur * P.H + oy0 + tn) * P.W + ox) * 64;
+                const unsigned gout = (unsigned)(((fcur * P.H + oy0 + tn) * P.W + ox) * 64 + 4 * q);
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm) {
                     float4 v = make_float4(acc[tm][tn][0] + bias4[tm].x, acc[tm][tn][1] + bias4[tm].y, acc[tm][tn][2] + bias4[tm].z, acc[tm][tn][3] + bias4[tm].w);
                     if constexpr (RES) { const float4 r4 = rpre[tm][tn]; v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
-                    store4_f32_or_bf16(P.y, gout + tm * 16 + 4 * q, v, OUT16 ? 1 : 0);
+                    if constexpr (OUT16) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, rsy, (gout + tm * 16) * 2u, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, rsy, (gout + tm * 16) * 4u, 0, 0);
                     ssum[tm][0] += v.x; ssum[tm][1] += v.y; ssum[tm][2] += v.z; ssum[tm][3] += v.w;
                     ssq[tm][0] += v.x * v.x; ssq[tm][1] += v.y * v.y; ssq[tm][2] += v.z * v.z; ssq[tm][3] += v.w * v.w;
                 }
@@ -645,6 +652,12 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
 // optional residual epilogue): 254 -> 245 us per launch at B = 64.  The prologue form was built the same way (every thread
 // transforming the pieces it issued in place behind counted vmcnt waits, coefficients in registers) and measured SLOWER than the
 // register-staged conv64p_kernel (340 vs 323 us: the in-place pass adds a ds_read_b128 per piece and its waits), so it is not kept.
+#ifndef VDX_C64D_SWP
+#define VDX_C64D_SWP 0
+#endif
+#ifndef VDX_C64D_DIAG
+#define VDX_C64D_DIAG 0      // knock-out switches for timing experiments (tools/mkvariant.sh); the product build has none
+#endif
 constexpr int C64D_AROWS = 328;                       // 324 halo rows padded to 41 DMA instructions of 8 rows
 constexpr int C64D_APL = C64D_AROWS * 128;
 __device__ __attribute__((aligned(16))) unsigned g_zero_page_c64d[4];
@@ -743,7 +756,9 @@ __global__ __launch_bounds__(512) void conv64d_kernel(const ConvArgs P, const in
         if (more) {
             decode(t + 1, fn, tyn, txn);
             bn = fn / P.F;
+#if !(VDX_C64D_DIAG & 2)
             dma(t + 1, buf ^ 1);                      // the other buffer was last read during tile t - 1 (barrier since)
+#endif
         }
         f32x4 acc[4][2];
 #pragma unroll
@@ -758,6 +773,44 @@ __global__ __launch_bounds__(512) void conv64d_kernel(const ConvArgs P, const in
                     rpre[tm][tn] = *reinterpret_cast<const float4*>(P.res + ((size_t)(fcur * P.H + oy0 + tn) * P.W + ox) * 64 + tm * 16 + 4 * q);
         }
         const char* At = Al + buf * C64D_APL;
+#if VDX_C64D_DIAG & 4
+        uint4 af_once[4], bf_once[2];
+#endif
+#if VDX_C64D_SWP
+        // software pipeline over the 18 (tap, K chunk) steps: the 6 fragment reads of step s + 1 are issued BEFORE the 8 MFMAs of step s
+        // (two register sets), so an MFMA never waits a whole LDS round trip for reads issued right in front of it.  The compiler's own
+        // order puts each pair of reads 2-4 MFMAs ahead of its use with an s_waitcnt behind it: MFMA busy 45 % (profiles/r02_pmc_step.md)
+        auto frag_load = [&](int st, uint4 (&af)[4], uint4 (&bf)[2]) __attribute__((always_inline)) {
+            const int tap = st >> 1, ch = st & 1, dy = tap / 3, dx = tap % 3;
+            const int woff = swz(tap * 64 + lp, q);
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm) af[tm] = *reinterpret_cast<const uint4*>(Wl + ((woff + tm * 16 * 128) ^ (ch * 64)));
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(At + (swz(hpb[tn] + dy * 18 + dx, q) ^ (ch * 64)));
+        };
+        uint4 af[2][4], bf[2][2];
+        frag_load(0, af[0], bf[0]);
+#pragma unroll
+        for (int st = 0; st < 18; ++st) {
+            if (st + 1 < 18) frag_load(st + 1, af[(st + 1) & 1], bf[(st + 1) & 1]);
+#if VDX_C64D_SWP == 1
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int tm = 0; tm < 4; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) M::mma(acc[tm][tn], af[st & 1][tm], bf[st & 1][tn]);
+#if VDX_C64D_SWP == 1
+            __builtin_amdgcn_sched_barrier(0);
+#else
+            if (st + 1 < 18) {                                     // one read behind each of the first six MFMAs of the step
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            } else __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+#endif
+        }
+#else
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap % 3;
@@ -767,18 +820,34 @@ __global__ __launch_bounds__(512) void conv64d_kernel(const ConvArgs P, const in
             const int woff = swz(tap * 64 + lp, q);
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) {
+#if VDX_C64D_DIAG & 4
+                uint4 (&af)[4] = af_once; uint4 (&bf)[2] = bf_once;                     // diagnostic: no fragment reads inside the tap loop
+                if (tap == 0 && ch == 0) {
+#else
                 uint4 af[4], bf[2];
+                {
+#endif
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm) af[tm] = *reinterpret_cast<const uint4*>(Wl + ((woff + tm * 16 * 128) ^ (ch * 64)));
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(At + (boff[tn] ^ (ch * 64)));
+                }
+#if VDX_C64D_DIAG & 8
+#pragma unroll
+                for (int tm = 0; tm < 4; ++tm) acc[tm][0][0] += __uint_as_float((af[tm].x ^ bf[0].y ^ bf[1].z) & 0x3F800000u);      // diagnostic: reads only, no MFMA
+#else
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
+#endif
             }
         }
+#endif
         wait_vm<0>();                                 // the next tile has landed (before the stores below: the wait covers the DMA only)
+#if VDX_C64D_DIAG & 1
+        if (acc[0][0][0] == 12345.678f && acc[1][1][1] == 3.f && acc[2][0][2] == 1.f && acc[3][1][3] == 7.f)     // diagnostic: no epilogue (never true on real data)
+#endif
         {
             const int oy0 = tyc * 16 + 2 * wave, ox = txc * 16 + lp;
 #pragma unroll
@@ -830,7 +899,7 @@ static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
     const int grid = std::min(total, cus);
     const int tpb = (total + grid - 1) / grid;
     const int nblocks = (total + tpb - 1) / tpb;
-    const size_t lds = 9 * 64 * 128 + 2 * (size_t)C64_HALO * 128 + (64 + 64 + 64) * 4 + 128 * 8;
+    const size_t lds = 9 * 64 * 128 + 2 * (size_t)C64_HALO * 128 + (64 + 64 + 64) * 4 + 128 * 8 + 64 * 4;      // weights, 2 halo tiles, coefA / coefD / gmean, chs, bias
     auto launch = [&](auto kfn) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1237,7 +1306,7 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
         const int use64p = 1;
         const long tiles = (long)a.NF * (a.H / 16) * (a.W / 16);
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.C0 == 64 && a.C1 == 0 && a.Cout == 64 &&
-            a.wrows >= 64 && a.wrow0 >= 0 && a.wrow0 + 64 <= a.wrows && (!a.res || (!a.pro && a.x0_bf16 && !a.res_bf16)) && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
+            a.wrows >= 64 && a.wrow0 >= 0 && a.wrow0 + 64 <= a.wrows && (!a.res || (!a.pro && a.x0_bf16 && !a.res_bf16)) && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && npix * 64 * (a.y_bf16 ? 2 : 4) < 0xFFFFFFF0ull && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
             (!a.out_stats || (a.out_groups <= 32 && 64 % a.out_groups == 0))) {
             const bool dma_form = a.x0_bf16 && !a.pro;               // bf16 input, no prologue: input staged by LDS-DMA (conv64d_kernel)
             const ConvWork cw = conv_work(mode, a);
