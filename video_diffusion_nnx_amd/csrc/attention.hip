@@ -433,6 +433,9 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     // (ds_write_b128 over 8-lane groups at a 132-dword row stride: conflict-free) instead of two 8-byte pieces whose 16 rows collide two
     // by two (39 % of the kernel's LDS cycles were those conflicts: profiles/r02_pmc_step.md).  The out-projection's weight fragments
     // are loaded with the same permutation of K, so the product is unchanged.
+#ifndef VDX_H8_DIAG
+#define VDX_H8_DIAG 0        // knock-out switches for timing experiments (tools/mkvariant.sh); none in the product build
+#endif
 #ifndef VDX_H8_OSP
 #define VDX_H8_OSP 2
 #endif
@@ -517,8 +520,10 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
     }
     const float escale = P.scale * 1.44269504088896f;  // softmax(scale * s) = exp2((s - max s) * scale * log2 e) / sum
     // out-projection tiles of this wave
-    const int cot0 = (TNO == 4) ? h * TMO : (h & 3);
-    const int tn0 = (TNO == 4) ? 0 : 2 * (h >> 2);
+    // (TNO 4: a wave = TMO channel tiles x all 4 sequences; TNO 2: 4 channel tiles x 2 sequence pairs; TNO 1 -- C = 32, two channel tiles,
+    //  the YAML-literal config_v2_2's level 0 --: 2 channel tiles x 4 sequences)
+    const int cot0 = (TNO == 4) ? h * TMO : (TNO == 2) ? (h & 3) : (h & 1);
+    const int tn0 = (TNO == 4) ? 0 : (TNO == 2) ? 2 * (h >> 2) : (h >> 1);
     const char* wo = reinterpret_cast<const char*>(P.wo);
     uint4 wof[TMO][NCHO];
 #pragma unroll
@@ -526,7 +531,8 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
 #pragma unroll
         for (int ch = 0; ch < NCHO; ++ch)
         {
-            const char* wrow = wo + (size_t)((cot0 + tmo) * 16 + lp) * P.HDPad * M::ES + ch * 64;
+            const int orow = min((cot0 + tmo) * 16 + lp, P.C - 1);      // (TNO 1 with C < 32 never occurs: the launcher admits C = 32, 64, 128 only)
+            const char* wrow = wo + (size_t)orow * P.HDPad * M::ES + ch * 64;
             if constexpr (OSP) {
                 const uint2 lo = *reinterpret_cast<const uint2*>(wrow + q * 8), hi = *reinterpret_cast<const uint2*>(wrow + 32 + q * 8);
                 wof[tmo][ch] = make_uint4(lo.x, lo.y, hi.x, hi.y);
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
 #pragma unroll
                 for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-                    for (int ch = 0; ch < 2; ++ch) {
+                    for (int ch = 0; ch < (TNO == 1 ? 1 : 2); ++ch) {      // (C = 32: the second 32-channel chunk of the padded tile is zeros)
                         const uint4 xf = *reinterpret_cast<const uint4*>(xs + kt * PLANE + ((s0 + b) * 16 + lp) * RS + ch * 64 + q * 16);
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
@@ -687,10 +693,16 @@ __global__ __launch_bounds__(512) void attention_h8_kernel(const AttnArgs P, con
             if (do_a) {
 #pragma unroll
                 for (int u = 0; u < XP; ++u) xres[PAR][u] = xpre[u];
+#if !(VDX_H8_DIAG & 4)
                 if (more) fetch(sg_first + (long)(it + 1) * 4);
+#endif
+#if !(VDX_H8_DIAG & 1)
                 phase_a(smem + PAR * BUF, os2[PAR]);
+#endif
             }
+#if !(VDX_H8_DIAG & 2)
             if (it >= 1 && it - 1 < nv) phase_b(os2[PAR ^ 1], ys2[PAR ^ 1]);
+#endif
             if (do_a && more) put(smem + (PAR ^ 1) * BUF);
             __syncthreads();
         };
@@ -982,6 +994,7 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
             if (a.io_bf16 && a.C == 128 && a.L == 16) return launch_attn_h8_t<MODE, 2, 1, 4, true, false, true>(a, st);
             if (a.io_bf16 && a.C == 64) return launch_attn_h8_t<MODE, 1, 1, 2, true>(a, st);
             if (a.io_bf16 && a.C == 128) return launch_attn_h8_t<MODE, 2, 1, 4, true>(a, st);
+            if (a.io_bf16 && a.C == 32) return launch_attn_h8_t<MODE, 1, 1, 1, true>(a, st);      // dim 32 (configs/config_v2_2.yaml as written): level 0
         }
         if (a.C == 64 && nkt == 1) return launch_attn_h8_t<MODE, 1, 1, 2, false>(a, st);
         if (a.C == 64 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 2, false>(a, st);

@@ -395,6 +395,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
 // (with the GroupNorm/SiLU prologue applied) after its epilogue; one barrier per tile.  GroupNorm partial sums of the output stay
 // in registers across tiles and are flushed when the sample changes.  LDS rows are 128 bytes, unpadded, with the 16-byte chunk
 // index XOR-ed by (row & 7): conflict-free for the ds_read_b128 lane groups of 16 consecutive rows (MI355X_MICROARCH.md, LDS).
+#ifndef VDX_C64P_EARLY
+#define VDX_C64P_EARLY 0      // 1: issue the loads of tile t + 2 inside the tap loop of tile t (measured SLOWER: 495 vs 413 us, r03)
+#endif
+#ifndef VDX_C64P_DIAG
+#define VDX_C64P_DIAG 0      // knock-out switches of conv64p_kernel for timing experiments; none in the product build
+#endif
 constexpr int C64_HALO = 18 * 18;
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + 16 * (chunk ^ (row & 7)); }
 
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             const bool ok = (okmask >> u) & 1u;
             if (IN16) {
                 u32x4 v = sreg[u];
-                if (PRO) {
+                if (PRO && !(VDX_C64P_DIAG & 2)) {
                     float ca[PCH], cd[PCH];                           // (LDS broadcast-free reads: 4 x 16 B per piece; registers spilled, r02)
 #pragma unroll
                     for (int k = 0; k < PCH; k += 4) {
@@ -559,12 +565,17 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     stage_store(0);
     __syncthreads();
     int bcoef = bcur;                                 // sample the prologue coefficients in LDS belong to
+    // The global loads of tile t + 1 are issued as soon as the staging registers are free -- right after tile t has been written to LDS,
+    // i.e. inside the tap loop of tile t - 1 -- not at the top of tile t: the epilogue, the barrier and ~2 taps more of latency slack (the
+    // knock-out timings of round 3: tap loop and memory pipeline did not overlap, 224 us of 420 was the load -> LDS -> store skeleton alone)
+    bool preloaded = false;
     for (int t = t0; t < t1; ++t) {
         const int buf = (t - t0) & 1;
         const bool more = t + 1 < t1;
         int fn = fcur, tyn = tyc, txn = txc, bn = bcur;
         if (more) {
-            stage_load(t + 1);
+            if (!preloaded) stage_load(t + 1);
+            preloaded = false;
             decode(t + 1, fn, tyn, txn);
             bn = fn / P.F;
             if (bn != bcoef) { make_coef(bn); bcoef = bn; }          // uniform; nobody reads the coefficients during the MFMAs
@@ -592,10 +603,13 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             // With a prologue the write is VALU work (SiLU): two pieces per tap over three taps, and the two waves of a SIMD (w, w + 4)
             // take DIFFERENT taps, so one wave's VALU block runs under the other's MFMAs instead of both stalling the matrix pipe at once
             if (more) {
-                if (!PRO) { if (tap == 5) stage_store(buf ^ 1); }
+                if (!PRO) { if (tap == 5) { stage_store(buf ^ 1); if (VDX_C64P_EARLY && t + 2 < t1) { stage_load(t + 2); preloaded = true; } } }
                 else {
                     const int first = wave_u < 4 ? 4 : 6;
-                    if (tap >= 4 && tap - first >= 0 && tap - first < 3) stage_store(buf ^ 1, 2 * (tap - first), tap - first == 2 ? NU : 2 * (tap - first) + 2);
+                    if (tap >= 4 && tap - first >= 0 && tap - first < 3) {
+                        stage_store(buf ^ 1, 2 * (tap - first), tap - first == 2 ? NU : 2 * (tap - first) + 2);
+                        if (VDX_C64P_EARLY && tap - first == 2 && t + 2 < t1) { stage_load(t + 2); preloaded = true; }      // (wave-uniform)
+                    }
                 }
             }
             const int dy = tap / 3, dx = tap % 3;
@@ -604,7 +618,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             for (int tn = 0; tn < 2; ++tn) { const int hp = hpb[tn] + dy * 18 + dx; boff[tn] = swz(hp, q); }
             const int woff = swz(tap * 64 + lp, q);
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) {
+            for (int ch = 0; ch < ((VDX_C64P_DIAG & 4) ? 0 : 2); ++ch) {
                 uint4 af[4], bf[2];
 #pragma unroll
                 for (int tm = 0; tm < 4; ++tm) af[tm] = *reinterpret_cast<const uint4*>(Wl + ((woff + tm * 16 * 128) ^ (ch * 64)));
@@ -617,6 +631,9 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             }
         }
         // ---- epilogue of tile t ----
+#if VDX_C64P_DIAG & 1
+        if (acc[0][0][0] == 12345.678f && acc[1][1][1] == 3.f && acc[2][0][2] == 1.f && acc[3][1][3] == 7.f)     // diagnostic: no epilogue (never true on real data)
+#endif
         {
             const int oy0 = tyc * 16 + 2 * wave, ox = txc * 16 + lp;
             float4 bias4[4];
@@ -652,6 +669,9 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
 // optional residual epilogue): 254 -> 245 us per launch at B = 64.  The prologue form was built the same way (every thread
 // transforming the pieces it issued in place behind counted vmcnt waits, coefficients in registers) and measured SLOWER than the
 // register-staged conv64p_kernel (340 vs 323 us: the in-place pass adds a ds_read_b128 per piece and its waits), so it is not kept.
+#ifndef VDX_C64D_LATEWAIT
+#define VDX_C64D_LATEWAIT 1
+#endif
 #ifndef VDX_C64D_SWP
 #define VDX_C64D_SWP 0
 #endif
@@ -844,7 +864,9 @@ __global__ __launch_bounds__(512) void conv64d_kernel(const ConvArgs P, const in
             }
         }
 #endif
+#if !VDX_C64D_LATEWAIT
         wait_vm<0>();                                 // the next tile has landed (before the stores below: the wait covers the DMA only)
+#endif
 #if VDX_C64D_DIAG & 1
         if (acc[0][0][0] == 12345.678f && acc[1][1][1] == 3.f && acc[2][0][2] == 1.f && acc[3][1][3] == 7.f)     // diagnostic: no epilogue (never true on real data)
 #endif
@@ -863,6 +885,10 @@ __global__ __launch_bounds__(512) void conv64d_kernel(const ConvArgs P, const in
                 }
             }
         }
+#if VDX_C64D_LATEWAIT
+        wait_vm<8>();                                 // everything older than this tile's 8 stores -- the next tile's DMA -- has landed: the
+                                                      // epilogue's arithmetic and store issue overlap the tail of the DMA instead of following it
+#endif
         if (more && bn != bcur) { flush_stats(bcur); bcur = bn; }    // uniform: the next tile belongs to another sample
         fcur = fn; tyc = tyn; txc = txn;
         __syncthreads();                              // next tile landed everywhere; everybody is done reading this one
@@ -1308,7 +1334,10 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.C0 == 64 && a.C1 == 0 && a.Cout == 64 &&
             a.wrows >= 64 && a.wrow0 >= 0 && a.wrow0 + 64 <= a.wrows && (!a.res || (!a.pro && a.x0_bf16 && !a.res_bf16)) && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 && npix * 64 * (a.y_bf16 ? 2 : 4) < 0xFFFFFFF0ull && (!a.pro || (a.groups <= 32 && 64 % a.groups == 0)) &&
             (!a.out_stats || (a.out_groups <= 32 && 64 % a.out_groups == 0))) {
-            const bool dma_form = a.x0_bf16 && !a.pro;               // bf16 input, no prologue: input staged by LDS-DMA (conv64d_kernel)
+#ifndef VDX_C64_NODMA
+#define VDX_C64_NODMA 0
+#endif
+            const bool dma_form = a.x0_bf16 && !a.pro && !VDX_C64_NODMA;               // bf16 input, no prologue: input staged by LDS-DMA (conv64d_kernel)
             const ConvWork cw = conv_work(mode, a);
             LaunchScope ls(st, dma_form ? "conv64d_kernel" : "conv64p_kernel", cw.flops, cw.bytes, "<x16 %d, pro %d, y16 %d, res %d> %s", a.x0_bf16, a.pro, a.y_bf16, a.res ? 1 : 0, cw.shape);
             return dma_form ? launch_conv64d(a, st) : launch_conv64p(a, st);

@@ -584,8 +584,9 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
             for (int dt = 0; dt < 2; ++dt) cf[et][dt] = M::load_w4(ct + ((size_t)(et * 16 + lp) * 32 + dt * 16 + 4 * q) * M::ES);
     }
     // to_out tiles of this wave
-    const int cot0 = (TNO == 4) ? h * TMO : (h & 3);   // first output-channel tile
-    const int tn0 = (TNO == 4) ? 0 : 2 * (h >> 2);     // first pixel tile
+    // (TNO 1 = the C = 32 form -- level 0 of the YAML-literal config_v2_2 --: two output-channel tiles x four pixel tiles over the 8 waves)
+    const int cot0 = (TNO == 4) ? h * TMO : (TNO == 2) ? (h & 3) : (h & 1);   // first output-channel tile
+    const int tn0 = (TNO == 4) ? 0 : (TNO == 2) ? 2 * (h >> 2) : (h >> 1);     // first pixel tile
     const char* wo = reinterpret_cast<const char*>(P.wo);
     uint4 wof[WO_RES ? TMO : 1][WO_RES ? NCHO : 1];
     if (WO_RES) {
@@ -1014,10 +1015,11 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
     const bool generic_only = false;
     const int nkt = a.CPad / M::KT;
     if constexpr (MODE != MODE_F16)                           // (the one-wave-per-head kernels hard-code the bf16 / f32 register formats)
-    if (a.heads == 8 && a.C % 64 == 0 && !generic_only) {     // one wave per head; x tile double-buffered in LDS
+    if (a.heads == 8 && (a.C % 64 == 0 || a.C == 32) && !generic_only) {     // one wave per head; x tile double-buffered in LDS
         if constexpr (MODE == MODE_BF16) {
             if (a.io_bf16 && a.C == 64) return launch_sla8_t<MODE, 1, 1, 2, true>(a, st);
             if (a.io_bf16 && a.C == 128) return launch_sla8_t<MODE, 2, 1, 4, true>(a, st);
+            if (a.io_bf16 && a.C == 32) return launch_sla8_t<MODE, 1, 1, 1, true>(a, st);       // dim 32 (configs/config_v2_2.yaml as written): level 0
         }
         if (nkt == 1 && a.C == 64) return launch_sla8_t<MODE, 1, 1, 2, false>(a, st);
         if (nkt == 2 && a.C == 64) return launch_sla8_t<MODE, 2, 1, 2, false>(a, st);
