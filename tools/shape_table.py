@@ -3,7 +3,7 @@ step that `bench.py --launch-seq seq.json` wrote (library hook vdx_set_launch_ho
 FLOPs / bytes per launch).  One symbol serves several levels of the network, so per-symbol averages of `--stats` mix launches whose
 durations differ 4x; this table does not.
 
-    python tools/shape_table.py <rocprof dir with *kernel_trace.csv> <seq.json> [--md] [--skip-steps 3] [--take N] [--traffic out.json <pmc dir f> <pmc dir w>]
+    python tools/shape_table.py <rocprof dir with *kernel_trace.csv> <seq.json> [--md] [--skip-steps 3] [--take N] [--traffic out.json <pmc dir f> <pmc dir w>] [--pmc N]
 
 Alignment: the trace is walked in start-time order with a cursor into the step's sequence; a dispatch whose name contains the
 expected kernel name is assigned to that entry (the memset entry is optional: graph replays may not show it as a kernel), anything
@@ -96,6 +96,39 @@ def main():
                            '16-B-per-lane loads only); per (kernel | shape) averages, dispatches joined with the launch sequence by tools/shape_table.py',
                    'batch': meta['batch'], 'mode': meta['mode'], 'dim': meta['dim'], 'act': meta['act'], 'kernels': kernels}, open(out, 'w'), indent=1)
         print('wrote', out, len(kernels), 'keys')
+        return
+    if '--pmc' in args:
+        # per-(kernel | shape) counter table of tools/pmc_passes.sh runs of tools/bench_short.py: every dispatch of every counter_collection.csv
+        # under <root> is joined with the launch sequence; MFMA busy, LDS activity, bank-conflict share, split of wave life (MI355X_MICROARCH.md
+        # counter units: SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles per wave, SQ_VALU_MFMA_BUSY_CYCLES per SIMD, GRBM_GUI_ACTIVE per XCD)
+        acc = collections.defaultdict(lambda: collections.defaultdict(list))
+        for f in sorted(pathlib.Path(root).rglob('*counter_collection.csv')):
+            rows = list(csv.DictReader(open(f)))
+            by_counter = collections.defaultdict(list)
+            for r in rows:
+                by_counter[r['Counter_Name']].append(r)
+            for cname, rs in by_counter.items():
+                rs.sort(key=lambda r: int(r['Dispatch_Id']))
+                for st in align([r['Kernel_Name'] for r in rs], seq)[1:]:
+                    for i, j in st:
+                        acc[keys[j]][cname].append(float(rs[i]['Counter_Value']))
+        out = []
+        for k, d in acc.items():
+            if 'GRBM_GUI_ACTIVE' not in d or 'SQ_WAVE_CYCLES' not in d:
+                continue
+            avg = lambda c: sum(d[c]) / len(d[c]) if d.get(c) else 0.0
+            cyc = avg('GRBM_GUI_ACTIVE') / 8
+            wc = avg('SQ_WAVE_CYCLES')
+            out.append((cyc * len(d['GRBM_GUI_ACTIVE']), k, len(d['GRBM_GUI_ACTIVE']), cyc, avg('SQ_VALU_MFMA_BUSY_CYCLES') / 1024 / cyc,
+                        avg('SQ_LDS_IDX_ACTIVE') / 256 / cyc, avg('SQ_LDS_BANK_CONFLICT') / max(avg('SQ_LDS_IDX_ACTIVE'), 1.0),
+                        avg('SQ_WAIT_ANY') / wc, avg('SQ_WAIT_INST_ANY') / wc, avg('SQ_ACTIVE_INST_ANY') / wc))
+        out.sort(reverse=True)
+        print('| kernel | template arguments, shape | launches sampled | kernel cycles (GUI_ACTIVE / 8) | MFMA busy | LDS array active | bank-conflict share of LDS cycles | '
+              'wave life parked (`SQ_WAIT_ANY`) | issue-stalled (`SQ_WAIT_INST_ANY`) | issuing |')
+        print('|---|---|---|---|---|---|---|---|---|---|')
+        for r in out[:int(args[args.index('--pmc') + 1]) if args[args.index('--pmc') + 1].isdigit() else 30]:
+            kn, sh = r[1].split(' | ', 1)
+            print(f'| `{kn}` | {sh} | {r[2]} | {r[3] / 1e3:.0f} k | {100 * r[4]:.0f} % | {100 * r[5]:.0f} % | {100 * r[6]:.0f} % | {100 * r[7]:.0f} % | {100 * r[8]:.0f} % | {100 * r[9]:.0f} % |')
         return
     rows = load_rows(root, '*kernel_trace.csv')
     rows.sort(key=lambda r: int(r['Start_Timestamp']))

@@ -395,6 +395,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
 // (with the GroupNorm/SiLU prologue applied) after its epilogue; one barrier per tile.  GroupNorm partial sums of the output stay
 // in registers across tiles and are flushed when the sample changes.  LDS rows are 128 bytes, unpadded, with the 16-byte chunk
 // index XOR-ed by (row & 7): conflict-free for the ds_read_b128 lane groups of 16 consecutive rows (MI355X_MICROARCH.md, LDS).
+#ifndef VDX_C32_PRO_WAVES
+#define VDX_C32_PRO_WAVES 2     // waves per SIMD the C = 32 prologue form is compiled for: 2 = one workgroup per CU, no scratch (Y-shape step 9.66 ms); 4 = two per CU with 156 bytes of scratch (10.03 ms)
+#endif
 #ifndef VDX_C64P_EARLY
 #define VDX_C64P_EARLY 0      // 1: issue the loads of tile t + 2 inside the tap loop of tile t (measured SLOWER: 495 vs 413 us, r03)
 #endif
@@ -403,23 +406,35 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && TN == 2) ? 4 : 2) void conv_ig
 #endif
 constexpr int C64_HALO = 18 * 18;
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + 16 * (chunk ^ (row & 7)); }
+// the same for rows of C bf16 channels: C = 32 -> 64-byte rows of 4 chunks, chunk ^= 2 on rows with bit 2 set (conflict-free for the
+// ds_read_b128 lane groups of 16 consecutive rows and for 8-lane ds_write_b128 groups; brute-forced against the LDS banking table)
+template <int C> __device__ __forceinline__ int swz_c(int row, int chunk) {
+    if constexpr (C == 64) return row * 128 + 16 * (chunk ^ (row & 7));
+    else return row * 64 + 16 * (chunk ^ ((row >> 1) & 2));
+}
 
 // PRO / OUT16 / RES: prologue present, bf16 output, residual epilogue (plain form only: the data gradient of a ResnetBlock's first
 // conv) -- compile-time, so the unused path costs no registers or issue slots
-template <bool IN16, bool PRO, bool OUT16, bool RES = false>
-__global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
+// C = Cin = Cout: 64 (levels 0 / 1 of the N shape) or 32 (level 0 of the YAML-literal config_v2_2: one 32-deep K chunk, two output-channel
+// tiles, 64-byte LDS rows -- memory-bound, 36 MFMAs per wave and tile)
+template <bool IN16, bool PRO, bool OUT16, bool RES = false, int C = 64>
+__global__ __launch_bounds__(512, C == 32 ? (PRO ? VDX_C32_PRO_WAVES : 4) : 2) void conv64p_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
     using M = Mma<MODE_BF16>;
     constexpr int PCH = IN16 ? 8 : 4;                 // channels per 16-byte global piece
-    constexpr int PPR = 64 / PCH;                     // pieces per pixel
+    constexpr int PPR = C / PCH;                      // pieces per pixel
+    constexpr int RB = C * 2;                         // LDS row bytes (bf16)
+    constexpr int NTM = C / 16, NCH = C / 32;         // output-channel tiles, 32-deep K chunks
+    static_assert(C == 64 || (C == 32 && IN16 && !RES), "C = 32: bf16 tensors, no residual epilogue");
+    auto swz = [](int row, int chunk) __attribute__((always_inline)) { return swz_c<C>(row, chunk); };
     constexpr int NPIECE = C64_HALO * PPR;
     constexpr int NU = (NPIECE + 511) / 512;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Wl = smem;                                  // [9 * 64 rows][128 B]
-    char* Al = Wl + 9 * 64 * 128;                     // [2][324 rows][128 B]
-    float* coefA = reinterpret_cast<float*>(Al + 2 * C64_HALO * 128);
+    char* Wl = smem;                                  // [9 * C rows][RB]
+    char* Al = Wl + 9 * C * RB;                       // [2][324 rows][RB]
+    float* coefA = reinterpret_cast<float*>(Al + 2 * C64_HALO * RB);
     float* coefD = coefA + 64;
     float* gmean = coefD + 64;                        // [32][mean, rstd]
-    double* chs = reinterpret_cast<double*>(gmean + 64);   // [2][64] channel sum / sumsq of the current sample (f64: order-independent)
+    double* chs = reinterpret_cast<double*>(gmean + 64);   // [2][64] channel sum / sumsq of the current sample (f64: order-independent; [which * 64 + c])
     float* biasl = reinterpret_cast<float*>(chs + 128);    // [64] bias: read per tile in the epilogue (16 registers less to hold across the tap loop:
                                                            // the prologue form sat on the 256-register limit and spilled)
 
@@ -432,14 +447,14 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
 
     const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x0), 0, P.x0_bytes, 0x00020000);
     // output through a buffer descriptor too: 32-bit offsets instead of a 64-bit address per store (launcher: the tensor is < 4 GB)
-    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, (unsigned)P.NF * P.H * P.W * 64u * (OUT16 ? 2u : 4u), 0x00020000);
-    for (int i = tid; i < 9 * 64 * 8; i += 512) {     // packed [tap][wrows][64 ci] bf16: 128-byte rows; this conv's 64 rows start at wrow0
-        const int row = i >> 3, c = i & 7;            // (a slice of a wider packing: the data gradient of one half of a concat input)
-        const size_t srow = (size_t)(row >> 6) * P.wrows + P.wrow0 + (row & 63);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, (unsigned)P.NF * P.H * P.W * (unsigned)C * (OUT16 ? 2u : 4u), 0x00020000);
+    for (int i = tid; i < 9 * C * (RB / 16); i += 512) {     // packed [tap][wrows][CinPad = 64 ci] bf16: 128-byte rows; this conv's C rows start at wrow0
+        const int row = i / (RB / 16), c = i % (RB / 16);    // (a slice of a wider packing: the data gradient of one half of a concat input)
+        const size_t srow = (size_t)(row / C) * P.wrows + P.wrow0 + (row % C);
         *reinterpret_cast<uint4*>(Wl + swz(row, c)) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) + srow * 128 + c * 16);
     }
     if (tid < 128) chs[tid] = 0.0;
-    if (tid < 64) biasl[tid] = P.bias ? P.bias[tid] : 0.f;
+    if (tid < C) biasl[tid] = P.bias ? P.bias[tid] : 0.f;
 
     // per-thread staging pieces (constant over tiles): halo position, channel piece, LDS byte offset
     // (register budget: 256 at 2 waves per SIMD and the prologue forms sit on it -- the halo row / column share one register, the
@@ -466,12 +481,12 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             const int gy = ty * 16 - 1 + (pyx[u] >> 5), gx = tx * 16 - 1 + (pyx[u] & 31);
             const bool ok = gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
             okmask |= ok ? (1u << u) : 0u;
-            const unsigned off = ok ? (unsigned)(((f * P.H + gy) * P.W + gx) * 64 + pch0) * (IN16 ? 2u : 4u) : OOB;
+            const unsigned off = ok ? (unsigned)(((f * P.H + gy) * P.W + gx) * C + pch0) * (IN16 ? 2u : 4u) : OOB;
             sreg[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, off, 0, 0);
         }
     };
     auto stage_store = [&](int buf, int u0 = 0, int u1 = 64) {
-        char* dst = Al + buf * (C64_HALO * 128);
+        char* dst = Al + buf * (C64_HALO * RB);
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             if (u < u0 || u >= u1) continue;
@@ -513,26 +528,26 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
     // GroupNorm-apply coefficients of sample b (all threads call; ends with a barrier)
     auto make_coef = [&](int b) {
         if (!PRO) return;
-        gn_mean_rstd_wg(P.in_stats, b, P.groups, (double)P.F * P.H * P.W * (64 / P.groups), gmean, tid, 512);
+        gn_mean_rstd_wg(P.in_stats, b, P.groups, (double)P.F * P.H * P.W * (C / P.groups), gmean, tid, 512);
         __syncthreads();
-        if (tid < 64) {
-            const int g = tid / (64 / P.groups);
+        if (tid < C) {
+            const int g = tid / (C / P.groups);
             const float m = gmean[2 * g], rsd = gmean[2 * g + 1];
             float sc = 1.f, sh = 0.f;
-            if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + tid] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + 64 + tid]; }
+            if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + tid] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + C + tid]; }
             coefA[tid] = rsd * P.gamma[tid] * sc;
             coefD[tid] = (P.beta[tid] - m * rsd * P.gamma[tid]) * sc + sh;
         }
         __syncthreads();
     };
     // flush the register partial sums of sample b into out_stats (all threads call)
-    f32x4 ssum[4], ssq[4];
+    f32x4 ssum[NTM], ssq[NTM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ssum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int i = 0; i < NTM; ++i) { ssum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     auto flush_stats = [&](int b) {
         if (!P.out_stats) return;
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+        for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float s1 = reduce16(ssum[tm][e]), s2 = reduce16(ssq[tm][e]);
@@ -540,7 +555,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
                 ssum[tm][e] = 0.f; ssq[tm][e] = 0.f;
             }
         __syncthreads();
-        const int cpg = 64 / P.out_groups;
+        const int cpg = C / P.out_groups;
         if (tid < 2 * P.out_groups) {
             const int g = tid >> 1, which = tid & 1;
             double t = 0.0;
@@ -582,9 +597,9 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
         }
         // ---- 9 taps x 2 chunks x (4 x 2) MFMAs, no barrier; the next tile is written to the other buffer half way through,
         //      so its prologue arithmetic and LDS writes sit between MFMAs instead of after them ----
-        f32x4 acc[4][2];
+        f32x4 acc[NTM][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int i = 0; i < NTM; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // residual epilogue (the data gradient of a ResnetBlock's first conv: + the gradient of the skip path), plain form only:
         // fetched before the MFMAs so that the epilogue does not wait for it
         float4 rpre[RES ? 4 : 1][2];
@@ -596,7 +611,7 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
                 for (int tm = 0; tm < 4; ++tm)
                     rpre[tm][tn] = *reinterpret_cast<const float4*>(P.res + ((size_t)(fcur * P.H + oy0 + tn) * P.W + ox) * 64 + tm * 16 + 4 * q);   // fp32 res only: 8 plain loads, no format branch between them
         }
-        const char* At = Al + buf * (C64_HALO * 128);
+        const char* At = Al + buf * (C64_HALO * RB);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             // the next tile goes to the other buffer between the taps (loading two tiles ahead instead was measured slower: r02).
@@ -616,16 +631,16 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
             int boff[2];
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) { const int hp = hpb[tn] + dy * 18 + dx; boff[tn] = swz(hp, q); }
-            const int woff = swz(tap * 64 + lp, q);
+            const int woff = swz(tap * C + lp, q);
 #pragma unroll
-            for (int ch = 0; ch < ((VDX_C64P_DIAG & 4) ? 0 : 2); ++ch) {
-                uint4 af[4], bf[2];
+            for (int ch = 0; ch < ((VDX_C64P_DIAG & 4) ? 0 : NCH); ++ch) {
+                uint4 af[NTM], bf[2];
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm) af[tm] = *reinterpret_cast<const uint4*>(Wl + ((woff + tm * 16 * 128) ^ (ch * 64)));
+                for (int tm = 0; tm < NTM; ++tm) af[tm] = *reinterpret_cast<const uint4*>(Wl + ((woff + tm * 16 * RB) ^ (ch * 64)));
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) bf[tn] = *reinterpret_cast<const uint4*>(At + (boff[tn] ^ (ch * 64)));
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm)
+                for (int tm = 0; tm < NTM; ++tm)
 #pragma unroll
                     for (int tn = 0; tn < 2; ++tn) M::mma(acc[tm][tn], af[tm], bf[tn]);
             }
@@ -636,14 +651,14 @@ __global__ __launch_bounds__(512) void conv64p_kernel(const ConvArgs P, const in
 #endif
         {
             const int oy0 = tyc * 16 + 2 * wave, ox = txc * 16 + lp;
-            float4 bias4[4];
+            float4 bias4[NTM];
 #pragma unroll
-            for (int tm = 0; tm < 4; ++tm) bias4[tm] = *reinterpret_cast<const float4*>(biasl + tm * 16 + 4 * q);
+            for (int tm = 0; tm < NTM; ++tm) bias4[tm] = *reinterpret_cast<const float4*>(biasl + tm * 16 + 4 * q);
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) {
-                const unsigned gout = (unsigned)(((fcur * P.H + oy0 + tn) * P.W + ox) * 64 + 4 * q);
+                const unsigned gout = (unsigned)(((fcur * P.H + oy0 + tn) * P.W + ox) * C + 4 * q);
 #pragma unroll
-                for (int tm = 0; tm < 4; ++tm) {
+                for (int tm = 0; tm < NTM; ++tm) {
                     float4 v = make_float4(acc[tm][tn][0] + bias4[tm].x, acc[tm][tn][1] + bias4[tm].y, acc[tm][tn][2] + bias4[tm].z, acc[tm][tn][3] + bias4[tm].w);
                     if constexpr (RES) { const float4 r4 = rpre[tm][tn]; v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w; }
                     if constexpr (OUT16) __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)}, rsy, (gout + tm * 16) * 2u, 0, 0);
@@ -933,6 +948,16 @@ static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
         return hipGetLastError();
     };
     const int v = (a.x0_bf16 ? 4 : 0) | (a.pro ? 2 : 0) | (a.y_bf16 ? 1 : 0);
+    if (a.Cout == 32) {                               // C = 32 form: bf16 tensors only; 62 KB of LDS, two workgroups per CU
+        if (!a.x0_bf16 || !a.y_bf16 || a.res) return hipErrorInvalidValue;
+        const int grid2 = std::min(total, ((a.pro ? VDX_C32_PRO_WAVES : 4) / 2) * cus), tpb2 = (total + grid2 - 1) / grid2, nb2 = (total + tpb2 - 1) / tpb2;
+        const size_t lds2 = 9 * 32 * 64 + 2 * (size_t)C64_HALO * 64 + (64 + 64 + 64) * 4 + 128 * 8 + 64 * 4;
+        auto launch2 = [&](auto kfn) -> hipError_t {
+            hipLaunchKernelGGL(kfn, dim3(nb2), dim3(512), lds2, st, a, tpb2, total);
+            return hipGetLastError();
+        };
+        return a.pro ? launch2(conv64p_kernel<true, true, true, false, 32>) : launch2(conv64p_kernel<true, false, true, false, 32>);
+    }
     if (a.res) {
         if (a.pro || !a.x0_bf16 || a.res_bf16) return hipErrorInvalidValue;      // (the fp32-input form with 32 more registers would spill)
         return a.y_bf16 ? launch(conv64p_kernel<true, false, true, true>) : launch(conv64p_kernel<true, false, false, true>);
@@ -1341,6 +1366,14 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
             const ConvWork cw = conv_work(mode, a);
             LaunchScope ls(st, dma_form ? "conv64d_kernel" : "conv64p_kernel", cw.flops, cw.bytes, "<x16 %d, pro %d, y16 %d, res %d> %s", a.x0_bf16, a.pro, a.y_bf16, a.res ? 1 : 0, cw.shape);
             return dma_form ? launch_conv64d(a, st) : launch_conv64p(a, st);
+        }
+        // level 0 of dim-32 networks (the YAML-literal config_v2_2): the same kernel with 32-channel tiles, bf16 tensors
+        if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.C0 == 32 && a.C1 == 0 && a.Cout == 32 && a.wrows == 32 &&
+            a.wrow0 == 0 && a.CinPad == 64 && a.x0_bf16 && a.y_bf16 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 && tiles >= 1024 &&
+            (!a.pro || (a.groups <= 32 && 32 % a.groups == 0)) && (!a.out_stats || (a.out_groups <= 32 && 32 % a.out_groups == 0))) {
+            const ConvWork cw = conv_work(mode, a);
+            LaunchScope ls(st, "conv64p_kernel", cw.flops, cw.bytes, "<x16 1, pro %d, y16 1, res 0, C 32> %s", a.pro, cw.shape);
+            return launch_conv64p(a, st);
         }
         const bool in16c = a.x0_bf16 && (!a.C1 || a.x1_bf16);
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.Cout == 64 && in16c && !a.pro &&

@@ -212,16 +212,24 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(TimeMlpArgs P, const 
             if (part == 0) { float acc = 0.f; for (int b = 0; b < B; ++b) acc += dtemb[(size_t)b * P.temb_dim + n]; db2[n] += acc; }
         }
     }
-    // dl1[b][k] = (sum_n dt_b[n] W2[k][n]) * gelu'(lin1_b[k])      for k = n0 + col, samples strided over the 4 parts
-    for (int b = part; b < B; b += 4) {
-        const int k = n0 + col;
-        float acc = 0.f;
-        if (k < td) {
-            const float* dt = dtemb + (size_t)b * P.temb_dim;
-            for (int n = 0; n < td; ++n) acc = fmaf(dt[n], P.w2[(size_t)k * td + n], acc);
-            acc *= dgelu_tanh_b(lin1[b * td + k]);
+    // dl1[b][k] = (sum_n dt_b[n] W2[k][n]) * gelu'(lin1_b[k])      for k = n0 + 0..63: wave `part` takes 16 rows k, a row of W2 is read ONCE
+    // by the whole wave (lane = n: coalesced) for all samples, the dot products are reduced with shuffles.  (First form: one thread per k
+    // walking its own row -- 256 dependent, uncoalesced loads per thread: 244 us for 0.3 MFLOP on the critical path of the stem stage.)
+    {
+        const int lane = tid & 63;
+        for (int kk = 0; kk < 16; ++kk) {
+            const int kc = part * 16 + kk, k = n0 + kc;
+            if (k >= td) break;                                       // (wave-uniform)
+            for (int b = 0; b < B; ++b) {
+                const float* dt = dtemb + (size_t)b * P.temb_dim;
+                float acc = 0.f;
+                for (int n = lane; n < td; n += 64) acc = fmaf(dt[n], P.w2[(size_t)k * td + n], acc);
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+                if (lane == 0) dl1[b * 64 + kc] = acc * dgelu_tanh_b(lin1[b * td + k]);
+            }
         }
-        dl1[b * 64 + col] = acc;
+        for (int i = tid; i < B * 64; i += 256) if (n0 + (i & 63) >= td) dl1[i] = 0.f;      // columns beyond the hidden width
     }
     __syncthreads();
     {   // db1[k] += sum_b dl1_b[k],  dW1[j][k] += sum_b emb_b[j] dl1_b[k]

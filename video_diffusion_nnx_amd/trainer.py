@@ -269,10 +269,25 @@ class Trainer:
         lo, hi = self.rank * self.per_device_bs, (self.rank + 1) * self.per_device_bs
         # this rank's shard of every batch (P('data', None), trainer.py:309), staged one batch ahead on a side stream
         shards = DevicePrefetcher(self.dl, self.device, select=lambda b: b[lo:hi])
+        # trace hook (reference trainer.py:524-533,607: jax.profiler trace from the first step until profile_flush_step): every step up to
+        # profile_flush_step is one roctx range ("train_step N", via torch.cuda.nvtx = roctx on ROCm), so `rocprofv3 --marker-trace
+        # --kernel-trace -- python train.py ...` groups the kernels per step; no-op without the marker library
+        def _range(push, name=''):
+            try:
+                import torch.cuda.nvtx as nvtx
+                nvtx.range_push(name) if push else nvtx.range_pop()
+            except Exception:                                    # marker library absent: tracing is optional
+                pass
+        first_step = self.step
         while self.step < self.train_num_steps:
             shard = next(shards)
             t0 = time.time()
+            traced = self.device.type == 'cuda' and self.step - first_step < max(0, int(self.profile_flush_step))
+            if traced:
+                _range(True, f'train_step {self.step}')
             loss = self.train_step(shard, self.step)
+            if traced:
+                _range(False)
             if self.dist_on and self.world > 1:                  # global mean loss = mean of equal-size shard means (C2)
                 dist.all_reduce(loss, op=dist.ReduceOp.SUM)
                 loss = loss / self.world
