@@ -530,13 +530,15 @@ __global__ __launch_bounds__(512, C == 32 ? (PRO ? VDX_C32_PRO_WAVES : 4) : 2) v
         if (!PRO) return;
         gn_mean_rstd_wg(P.in_stats, b, P.groups, (double)P.F * P.H * P.W * (C / P.groups), gmean, tid, 512);
         __syncthreads();
-        if (tid < C) {
-            const int g = tid / (C / P.groups);
+        int tt = tid;
+        asm volatile("" : "+v"(tt));                  // opaque copy: the addresses below are formed here, per call, instead of being held (and spilled) across the tile loop
+        if (tt < C) {
+            const int g = tt / (C / P.groups);
             const float m = gmean[2 * g], rsd = gmean[2 * g + 1];
             float sc = 1.f, sh = 0.f;
-            if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + tid] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + C + tid]; }
-            coefA[tid] = rsd * P.gamma[tid] * sc;
-            coefD[tid] = (P.beta[tid] - m * rsd * P.gamma[tid]) * sc + sh;
+            if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + tt] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + C + tt]; }
+            coefA[tt] = rsd * P.gamma[tt] * sc;
+            coefD[tt] = (P.beta[tt] - m * rsd * P.gamma[tt]) * sc + sh;
         }
         __syncthreads();
     };
@@ -556,8 +558,10 @@ __global__ __launch_bounds__(512, C == 32 ? (PRO ? VDX_C32_PRO_WAVES : 4) : 2) v
             }
         __syncthreads();
         const int cpg = C / P.out_groups;
-        if (tid < 2 * P.out_groups) {
-            const int g = tid >> 1, which = tid & 1;
+        int tt = tid;
+        asm volatile("" : "+v"(tt));
+        if (tt < 2 * P.out_groups) {
+            const int g = tt >> 1, which = tt & 1;
             double t = 0.0;
             for (int c = g * cpg; c < (g + 1) * cpg; ++c) t += chs[which * 64 + c];
             unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * P.out_groups + g) * 2 + which, t);

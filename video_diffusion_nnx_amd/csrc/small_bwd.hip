@@ -28,11 +28,25 @@ __global__ __launch_bounds__(256) void final_conv_dw_kernel(const float* __restr
     __shared__ float red[256 * 4];
     const int c = threadIdx.x % D, pl = threadIdx.x / D, PL = 256 / D;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (pl < PL)
-        for (long pix = (long)blockIdx.x * PL + pl; pix < npix; pix += (long)gridDim.x * PL) {
-            const float xv = x_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(x)[pix * D + c] << 16) : x[pix * D + c];
-            for (int co = 0; co < Cout; ++co) { const float d = dout[pix * Cout + co]; acc[co] = fmaf(xv, d, acc[co]); accb[co] += d; }
+    if (pl < PL) {
+        // 8 pixels per pass, every load issued before the first use (one dependent load per pass was a 128-step latency chain: 112 us)
+        const long stride = (long)gridDim.x * PL;
+        for (long pix0 = (long)blockIdx.x * PL + pl; pix0 < npix; pix0 += stride * 8) {
+            float xv[8], dv[8][4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long pix = pix0 + u * stride;
+                const bool ok = pix < npix;
+                const long pe = ok ? pix : 0;
+                xv[u] = x_bf16 ? __uint_as_float((unsigned)reinterpret_cast<const unsigned short*>(x)[pe * D + c] << 16) : x[pe * D + c];
+                if (!ok) xv[u] = 0.f;
+                for (int co = 0; co < 4; ++co) dv[u][co] = (ok && co < Cout) ? dout[pe * Cout + co] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                for (int co = 0; co < 4; ++co) { acc[co] = fmaf(xv[u], dv[u][co], acc[co]); accb[co] += dv[u][co]; }
         }
+    }
     for (int co = 0; co < Cout; ++co) {
         __syncthreads();
         red[threadIdx.x] = (pl < PL) ? acc[co] : 0.f;
@@ -195,7 +209,14 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(TimeMlpArgs P, const 
     for (int i = tid; i < B * td; i += 256) {
         const int b = i / td, n = i - b * td;
         float acc = P.b1[n];
-        for (int k = 0; k < dim; ++k) acc = fmaf(emb[b * dim + k], P.w1[(size_t)k * td + n], acc);
+        // (8 weight loads in flight per pass: one dependent L2 round trip per k made this loop a 64-step latency chain on 4 workgroups)
+        for (int k0 = 0; k0 < dim; k0 += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = (k0 + u < dim) ? P.w1[(size_t)(k0 + u) * td + n] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (k0 + u < dim) acc = fmaf(emb[b * dim + k0 + u], wv[u], acc);
+        }
         lin1[i] = acc; h[i] = gelu_tanh_b(acc);
     }
     __syncthreads();
@@ -204,10 +225,18 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(TimeMlpArgs P, const 
         const int n = n0 + col;
         if (n < td) {
             const int kper = (td + 3) / 4;
-            for (int k = part * kper; k < min(td, (part + 1) * kper); ++k) {
-                float acc = 0.f;
-                for (int b = 0; b < B; ++b) acc = fmaf(h[b * td + k], dtemb[(size_t)b * P.temb_dim + n], acc);
-                dw2[(size_t)k * td + n] += acc;
+            const int k1 = min(td, (part + 1) * kper);
+            for (int k0 = part * kper; k0 < k1; k0 += 8) {             // 8 read-modify-writes of dW2 in flight
+                float old[8], acc[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { old[u] = (k0 + u < k1) ? dw2[(size_t)(k0 + u) * td + n] : 0.f; acc[u] = 0.f; }
+                for (int b = 0; b < B; ++b) {
+                    const float dt = dtemb[(size_t)b * P.temb_dim + n];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (k0 + u < k1) acc[u] = fmaf(h[b * td + k0 + u], dt, acc[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (k0 + u < k1) dw2[(size_t)(k0 + u) * td + n] = old[u] + acc[u];
             }
             if (part == 0) { float acc = 0.f; for (int b = 0; b < B; ++b) acc += dtemb[(size_t)b * P.temb_dim + n]; db2[n] += acc; }
         }
