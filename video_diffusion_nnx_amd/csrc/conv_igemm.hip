@@ -937,6 +937,211 @@ static hipError_t launch_conv64d(const ConvArgs& a, hipStream_t st) {
     return a.y_bf16 ? launch(conv64d_kernel<true, false>) : launch(conv64d_kernel<false, false>);
 }
 
+// ---- weights-in-registers form of the persistent 64 -> 64 conv (bf16 tensors, no prologue): "conv64r" ---------------------------------
+// conv64d_kernel keeps the 72 KB weight image in LDS beside TWO input tiles: one 41 KB tile in flight per CU against a ~3 us DMA round
+// trip in a 4.9 us tile period, and every MFMA step reads 4 weight + 2 pixel fragments from LDS (knock-out timings of round 3: the
+// load -> LDS -> store skeleton and the tap loop do not overlap).  Here a wave owns 32 output channels x 64 pixels (4 rows of the 16 x 16
+// tile) and keeps ITS weights -- 9 taps x 2 K chunks x 2 channel tiles = 36 A fragments, 144 registers -- for the whole tile walk:
+// no weight image in LDS, so THREE input tiles fit (two tiles of LDS-DMA in flight: a tile has two periods to land), and a step reads 4
+// pixel fragments for 8 MFMAs (72 reads per wave and tile instead of 108).  Swizzle key of a halo row = its COLUMN, so a fragment address
+// is a register per (dx, K chunk) + the wave's row base + an immediate.
+#ifndef VDX_C64R_DIAG
+#define VDX_C64R_DIAG 0            // timing knock-outs (wrong results): 1 = no MFMAs, 2 = no fragment reads
+#endif
+template <bool OUT16>
+__global__ __launch_bounds__(512) void conv64r_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
+    using M = Mma<MODE_BF16>;
+    constexpr int NDMA = 41, NK = (NDMA + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Al = smem;                                  // [3][328 rows][128 B]
+    double* chs = reinterpret_cast<double*>(Al + 3 * C64D_APL);   // [2][64] channel sum / sumsq of the current sample (f64: order-independent)
+    float* biasl = reinterpret_cast<float*>(chs + 128);           // [64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave_u & 1, wp = wave_u >> 1;     // output-channel half, pixel quarter (rows 4 wp .. 4 wp + 3)
+    const int lp = lane & 15, q = lane >> 4;
+    const int tiles_x = P.W >> 4, tiles_pf = tiles_x * (P.H >> 4);
+    const int t0 = blockIdx.x * tiles_per_block, t1 = min(t0 + tiles_per_block, total_tiles);
+    if (t0 >= t1) return;
+
+    // this wave's weights: packed [tap][wrows][64 ci] bf16, 16 bytes = ci 32 ch + 8 q .. + 7.  Row lp of channel tile tm is output channel
+    // wc * 32 + 8 (lp >> 2) + 4 tm + (lp & 3): the accumulator rows 4 q .. 4 q + 3 of the two tiles are then 8 CONSECUTIVE channels of a lane
+    // (one 16-byte store per pixel in the bf16 form)
+    uint4 wf[9][2][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+                wf[tap][ch][tm] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) +
+                    ((size_t)tap * P.wrows + P.wrow0 + wc * 32 + 8 * (lp >> 2) + 4 * tm + (lp & 3)) * 128 + ch * 64 + q * 16);
+    if (tid < 128) chs[tid] = 0.0;
+    if (tid < 64) biasl[tid] = P.bias ? P.bias[tid] : 0.f;
+
+    // DMA pieces of this lane: instruction u = wave + 8 k covers halo rows 8 u .. 8 u + 7; the lane's row is hp = 8 u + (lane >> 3), its LDS
+    // position lane & 7 holds source chunk (lane & 7) ^ (hx & 7) with hx = hp % 18 (column key).  The piece geometry is recomputed per
+    // tile from an OPAQUE copy of the lane id: held in registers (or hoisted by the compiler) it is what spills next to 144 weight registers.
+    const char* const zero_page = reinterpret_cast<const char*>(g_zero_page_c64d);
+    const char* const xb = reinterpret_cast<const char*>(P.x0);
+    const unsigned al_base = lds_addr(Al);
+    auto decode = [&](int t, int& f, int& ty, int& tx) { f = t / tiles_pf; const int r = t - f * tiles_pf; ty = r / tiles_x; tx = r - ty * tiles_x; };
+    auto dma = [&](int t, int buf) {
+        int f, ty, tx; decode(t, f, ty, tx);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const unsigned dst = al_base + buf * C64D_APL + wave_u * 1024;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            if (wave_u + 8 * k >= NDMA) continue;     // (uniform)
+            const int hp = (wave_u + 8 * k) * 8 + (ln >> 3);
+            const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;          // hp / 18, hp % 18 for hp < 328
+            const int gy = ty * 16 - 1 + hy, gx = tx * 16 - 1 + hx;
+            const bool ok = hp < C64_HALO && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+            const size_t off = (size_t)((f * P.H + gy) * P.W + gx) * 128 + (((ln & 7) ^ (hx & 7)) << 4);
+            glds16(ok ? static_cast<const void*>(xb + off) : static_cast<const void*>(zero_page), dst + k * 8 * 1024);
+        }
+    };
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, (unsigned)P.NF * P.H * P.W * 64u * (OUT16 ? 2u : 4u), 0x00020000);
+    f32x4 ssum[2], ssq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ssum[i] = f32x4{0.f, 0.f, 0.f, 0.f}; ssq[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    auto flush_stats = [&](int b) {
+        if (!P.out_stats) return;
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float s1 = reduce16(ssum[tm][e]), s2 = reduce16(ssq[tm][e]);
+                const int c = wc * 32 + 8 * q + 4 * tm + e;
+                if (lp == 0) { unsafeAtomicAdd(&chs[c], (double)s1); unsafeAtomicAdd(&chs[64 + c], (double)s2); }
+                ssum[tm][e] = 0.f; ssq[tm][e] = 0.f;
+            }
+        __syncthreads();
+        const int cpg = 64 / P.out_groups;
+        int tt = tid;
+        asm volatile("" : "+v"(tt));
+        if (tt < 2 * P.out_groups) {
+            const int g = tt >> 1, which = tt & 1;
+            double t = 0.0;
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) t += chs[which * 64 + c];
+            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * P.out_groups + g) * 2 + which, t);
+        }
+        __syncthreads();
+        if (tid < 128) chs[tid] = 0.0;
+        __syncthreads();
+    };
+
+    // fragment addressing (see the header): B fragment of (tn, dy, dx, ch) = At + rowbase + bdx[dx][ch] + (tn + dy) * 18 * 128
+    int bdx[3][2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) { const int hx = lp + dx; bdx[dx][ch] = hx * 128 + 16 * ((q + 4 * ch) ^ (hx & 7)); }
+    const int rowbase = (4 * wp) * 18 * 128;           // (wave-uniform)
+
+    int fcur, tyc, txc;
+    decode(t0, fcur, tyc, txc);
+    int bcur = fcur / P.F;
+    __syncthreads();                                  // chs + bias visible
+    dma(t0, 0);
+    if (t0 + 1 < t1) { dma(t0 + 1, 1); wait_vm<5>(); } else wait_vm<0>();      // tile t0 has landed (a wave issues 5 or 6 instructions per tile)
+    __syncthreads();
+    int buf = 0;
+    for (int t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1, more2 = t + 2 < t1;
+        int fn = fcur, tyn = tyc, txn = txc, bn = bcur;
+        if (more) { decode(t + 1, fn, tyn, txn); bn = fn / P.F; }
+        if (more2) dma(t + 2, buf >= 1 ? buf - 1 : 2);    // (buf + 2) % 3: the buffer of tile t - 1, last read before the previous barrier
+        const char* At = Al + buf * C64D_APL + rowbase;
+        const int oy0 = tyc * 16 + 4 * wp, ox = txc * 16 + lp;
+        // Sliding window over the wave's 6 halo rows: a fragment of halo row hr serves output rows hr, hr - 1, hr - 2 (taps dy = 0, 1, 2: all
+        // weights are in registers), so a tile costs 36 fragment reads per wave; at most three rows of accumulators are live, a row is
+        // finished (bias, statistics, store) as soon as halo row hr = row + 2 has been consumed.
+        f32x4 acc[2][4];
+        uint4 bf[2][3];                                  // fragments of step s = 2 hr + ch in bf[s & 1]: step s + 1 is read before step s's MFMAs
+        auto frag_read = [&](uint4 (&d)[3], int hr, int ch) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                if constexpr (VDX_C64R_DIAG & 2) d[dx] = uint4{(unsigned)lane, (unsigned)dx, (unsigned)t, (unsigned)ch};
+                else d[dx] = *reinterpret_cast<const uint4*>(At + bdx[dx][ch] + hr * (18 * 128));
+            }
+        };
+        frag_read(bf[0], 0, 0);
+#pragma unroll
+        for (int hr = 0; hr < 6; ++hr) {
+            if (hr < 4) { acc[0][hr] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][hr] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) {
+                const int s_ = 2 * hr + ch;
+                if (s_ + 1 < 12) frag_read(bf[(s_ + 1) & 1], (s_ + 1) >> 1, (s_ + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) {
+                        const int tn = hr - dy;
+                        if (tn < 0 || tn > 3) continue;
+#pragma unroll
+                        for (int tm = 0; tm < 2; ++tm) {
+                            if constexpr (VDX_C64R_DIAG & 1) acc[tm][tn][0] += __uint_as_float(bf[s_ & 1][dx].x ^ wf[dy * 3 + dx][ch][tm].x);
+                            else M::mma(acc[tm][tn], wf[dy * 3 + dx][ch][tm], bf[s_ & 1][dx]);
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (hr >= 2) {
+                const int tn = hr - 2;
+                float4 bias4[2];
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) bias4[tm] = *reinterpret_cast<const float4*>(biasl + wc * 32 + 8 * q + 4 * tm);
+                const unsigned gout = (unsigned)(((fcur * P.H + oy0 + tn) * P.W + ox) * 64 + wc * 32 + 8 * q);
+                float4 v[2];
+#pragma unroll
+                for (int tm = 0; tm < 2; ++tm) {
+                    v[tm] = make_float4(acc[tm][tn][0] + bias4[tm].x, acc[tm][tn][1] + bias4[tm].y, acc[tm][tn][2] + bias4[tm].z, acc[tm][tn][3] + bias4[tm].w);
+                    ssum[tm][0] += v[tm].x; ssum[tm][1] += v[tm].y; ssum[tm][2] += v[tm].z; ssum[tm][3] += v[tm].w;
+                    ssq[tm][0] += v[tm].x * v[tm].x; ssq[tm][1] += v[tm].y * v[tm].y; ssq[tm][2] += v[tm].z * v[tm].z; ssq[tm][3] += v[tm].w * v[tm].w;
+                }
+                if constexpr (OUT16)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_bf16x2(v[0].x, v[0].y), pack_bf16x2(v[0].z, v[0].w), pack_bf16x2(v[1].x, v[1].y), pack_bf16x2(v[1].z, v[1].w)}, rsy, gout * 2u, 0, 0);
+                else {
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[tm].x), __float_as_uint(v[tm].y), __float_as_uint(v[tm].z), __float_as_uint(v[tm].w)}, rsy, (gout + 4 * tm) * 4u, 0, 0);
+                }
+            }
+        }
+        // tile t + 1 has landed: everything older than this iteration's DMA (5 or 6 instructions, when issued) and its 4 or 8 stores
+        constexpr int NST = OUT16 ? 4 : 8;
+        if (more2) wait_vm<5 + NST>(); else wait_vm<NST>();
+        if (more && bn != bcur) { flush_stats(bcur); bcur = bn; }    // uniform: the next tile belongs to another sample
+        fcur = fn; tyc = tyn; txc = txn;
+        buf = buf == 2 ? 0 : buf + 1;
+        __syncthreads();                              // tile t + 1 landed everywhere; everybody is done reading tile t
+    }
+    flush_stats(bcur);
+}
+
+static hipError_t launch_conv64r(const ConvArgs& a, hipStream_t st) {
+    const int total = a.NF * (a.H >> 4) * (a.W >> 4);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const int grid = std::min(total, cus);
+    const int tpb = (total + grid - 1) / grid;
+    const int nblocks = (total + tpb - 1) / tpb;
+    const size_t lds = 3 * (size_t)C64D_APL + 128 * 8 + 64 * 4;
+    auto launch = [&](auto kfn) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(512), lds, st, a, tpb, total);
+        return hipGetLastError();
+    };
+    if (a.pro || !a.x0_bf16 || a.res) return hipErrorInvalidValue;
+    return a.y_bf16 ? launch(conv64r_kernel<true>) : launch(conv64r_kernel<false>);
+}
+
 static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
     const int total = a.NF * (a.H >> 4) * (a.W >> 4);
     int dev = 0, cus = 256;
@@ -1367,6 +1572,14 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
 #define VDX_C64_NODMA 0
 #endif
             const bool dma_form = a.x0_bf16 && !a.pro && !VDX_C64_NODMA;               // bf16 input, no prologue: input staged by LDS-DMA (conv64d_kernel)
+#ifndef VDX_C64R
+#define VDX_C64R 1
+#endif
+            if (VDX_C64R && dma_form && !a.res) {                     // weights in registers, three-deep tile ring (conv64r_kernel)
+                const ConvWork cw = conv_work(mode, a);
+                LaunchScope ls(st, "conv64r_kernel", cw.flops, cw.bytes, "<y16 %d> %s", a.y_bf16, cw.shape);
+                return launch_conv64r(a, st);
+            }
             const ConvWork cw = conv_work(mode, a);
             LaunchScope ls(st, dma_form ? "conv64d_kernel" : "conv64p_kernel", cw.flops, cw.bytes, "<x16 %d, pro %d, y16 %d, res %d> %s", a.x0_bf16, a.pro, a.y_bf16, a.res ? 1 : 0, cw.shape);
             return dma_form ? launch_conv64d(a, st) : launch_conv64p(a, st);
