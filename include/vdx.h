@@ -151,6 +151,13 @@ int vdx_attention_forward_ex(int mode, const float* x, float* y, const void* wqk
                              const void* wo_packed, const float* bo, int batch, int frames, int h, int w, int c, int heads,
                              int temporal, int fp8_core, void* stream);
 
+/* Same block on bf16 TENSORS (the form the network runs under bf16 activation storage, vdx_set_activation_storage): x and y are
+ * channel-last bf16 [batch, frames, h, w, c]; VDX_MODE_BF16 operands.  The level-0 shape of the N config (c = 64, 8 heads, temporal,
+ * 16 frames) runs attention_w_kernel (one wave per group of 4 sequences), other shapes the kernels of vdx_attention_forward. */
+int vdx_attention_forward_bf16(const void* x_bf16, void* y_bf16, const void* wqkv_packed, const float* bqkv,
+                               const void* wo_packed, const float* bo, int batch, int frames, int h, int w, int c, int heads,
+                               int temporal, int fp8_core, void* stream);
+
 /* SpatialLinearAttention + residual (reference: modules.py:64-129 inside Residual(PreNorm(..)), unet3d.py:170-178).
  * heads must be 8, head dim 32.  wq/wk/wv_packed: packed [C,256]; wo_packed: packed [256,C].
  * workspace: vdx_sla_workspace_bytes(mode, batch*frames, h*w, heads). */

@@ -173,6 +173,44 @@ def test_attention(mode, case):
     assert _rel(y.cpu().double(), ref) < TOL[mode]
 
 
+# The same block on bf16 TENSORS (bf16 activation storage), through vdx_attention_forward_bf16.  C = 64 with 16 frames and >= 256
+# sequences is attention_w_kernel (one wave per group of 4 sequences, all heads in the wave: the level-0 kernel of the N shape): 1, 2
+# and 3 groups per wave, a ragged last workgroup (waves without a group), groups on both sides of a sample boundary; the other cases
+# keep the one-wave-per-head kernels covered at block level.  The oracle sees the bf16-rounded input; the output is rounded to bf16
+# once more (2^-9 of |x + branch| against a branch of ~0.3 |x|), hence the wider stated tolerance on the branch alone.
+ATTN16_CASES = [
+    # B, F, H, W, C
+    (1, 16, 16, 16, 64),       # 64 groups: one per wave, 8 workgroups
+    (2, 16, 48, 47, 64),       # 1128 groups over two samples
+    (1, 16, 96, 93, 64),       # 2232 groups: 2 per wave, last workgroup has 8 groups for 8 waves x 2
+    (3, 16, 64, 48, 64),       # 2304 groups, 3 samples
+    (1, 16, 8, 8, 64),         # 64 sequences: below the threshold -> attention_h8_kernel FULL form
+    (1, 12, 16, 16, 64),       # 12 frames: masked attention_h8_kernel
+    (1, 16, 8, 8, 128),
+]
+
+
+@pytest.mark.parametrize('case', ATTN16_CASES)
+def test_attention_bf16_tensors(case):
+    from video_diffusion_nnx_amd import ops
+    B, Fr, H, W, C = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Fr, H, W, C, generator=g).bfloat16()
+    p = _mha_params(C, 8, g)
+    packed = ops.pack_mha(*[(p[f'a.{n}.kernel'].to(DEV), p[f'a.{n}.bias'].to(DEV)) for n in ('q', 'k', 'v', 'out')], 'bf16')
+    y = ops.attention_forward_bf16(x.to(DEV), packed, 8, True)
+    xd = x.double()
+    xt = xd.permute(0, 2, 3, 1, 4).reshape(B, H * W, Fr, C)
+    o = R.multihead_attention({k: v.double() for k, v in p.items()}, 'a', xt, 32).reshape(B, H, W, Fr, C).permute(0, 3, 1, 2, 4)
+    yd = y.cpu().double()
+    assert torch.isfinite(yd).all()
+    rel_branch, rel = _rel(yd - xd, o), _rel(yd, o + xd)
+    print(f'attention on bf16 tensors {case}: branch {rel_branch:.3e}, block {rel:.3e}')
+    assert rel_branch < 4e-2 and rel < 1e-2, (case, rel_branch, rel)
+    y2 = ops.attention_forward_bf16(x.to(DEV), packed, 8, True)
+    assert torch.equal(y, y2)                      # no order-dependent sums: bit-reproducible
+
+
 # fp8 attention core (vdx_set_attention_fp8 / BASELINE.json configs[4]): q, k, v and the softmax probabilities of the <= 16-token
 # blocks are rounded to e4m3 (3 mantissa bits: 2^-4 relative per element) before QK^T / PV.  No reference counterpart (parity
 # unpinned): checked against the fp64 oracle of the block.  Measured (r02): attention branch 4-7e-2 against 0.4-0.8e-2 with bf16

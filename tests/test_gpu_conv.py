@@ -107,17 +107,21 @@ def test_conv_concat_and_prologue(mode):
         assert _rel(y2.cpu().double(), ref2) < tol, (mode, use_ss, _rel(y2.cpu().double(), ref2))
 
 
-@pytest.mark.parametrize('act_bf16', [False, True])
-def test_persistent_c64_conv(act_bf16):
-    """The persistent level-0 specialisation (conv64p_kernel: 3x3, 64 -> 64 channels, bf16 mode, >= 1024 tiles of 16x16 pixels,
-    weights resident in LDS): plain form with statistics, then the fused-prologue form consuming it, two samples so that the
-    per-sample flush of the register-resident statistics and the coefficient switch are exercised; fp32 and bf16 tensors."""
+@pytest.mark.parametrize('act_bf16,B,Fr', [(False, 2, 32), (True, 2, 32), (True, 3, 22)])
+def test_persistent_c64_conv(act_bf16, B, Fr):
+    """The persistent level-0 specialisations (3x3, 64 -> 64 channels, bf16 mode, >= 1024 tiles of 16x16 pixels; fp32 tensors:
+    conv64p_kernel, weights resident in LDS; bf16 tensors: conv64r_kernel, weights in registers + a three-deep LDS-DMA tile ring, the
+    prologue applied in place one tile ahead): plain form with statistics, then the fused-prologue form consuming it, several samples
+    so that the per-sample flush of the register-resident statistics and the coefficient switch are exercised.  (3, 22): 1056 tiles = 5
+    per workgroup, so workgroups 70 and 140 walk ACROSS a sample boundary (tiles 352, 704)."""
     from video_diffusion_nnx_amd import ops
     dev = torch.device('cuda:0')
     g = torch.Generator().manual_seed(11)
-    B, Fr, H, W, C = 2, 32, 64, 64, 64                     # 64 frames x 16 tiles = 1024 tiles
+    H, W, C = 64, 64, 64                                   # (2, 32): 64 frames x 16 tiles = 1024 tiles
     x = torch.randn(B, Fr, H, W, C, generator=g)
     x[1] *= 1.7                                            # different statistics per sample
+    if B > 2:
+        x[2] = x[2] * 0.6 + 0.4
     kern = torch.randn(1, 3, 3, C, C, generator=g) / (9 * C) ** 0.5
     bias = torch.randn(C, generator=g)
     pw = ops.pack_conv_weights(kern.to(dev), 'bf16')

@@ -764,6 +764,222 @@ static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---- level 0 (C = 64, 16 tokens, 8 heads, bf16 tensors): one WAVE per group of 4 sequences, all heads in the wave ("attention_w") ------
+// attention_h8_kernel's knock-out timings add up: 310 us of load -> LDS -> store skeleton + 383 us of per-head attention +
+// 111 us of out-projection = the 780 us it takes -- its waves walk the phases of a sub-tile in lockstep (heads meet in LDS twice per
+// tile), so memory, VALU and matrix work of a CU never overlap.  Here nothing is shared between waves but the weights: a persistent
+// workgroup per CU keeps the q|k|v image (768 x 64 bf16 = 96 KB) and the out-projection image (64 x 256 = 32 KB) in LDS, and each of its
+// 8 waves walks its own groups of 4 adjacent sequences with NO workgroup barrier and NO activation byte in LDS:
+//   * the x rows of a sequence are fetched straight into MFMA fragments (lane (token, q) = 16 bytes of a 64-byte K chunk; the 4 sequences
+//     of a group are 4 adjacent pixels, so a token's 4 x 128 bytes are one contiguous run) one group ahead, and ARE the residual;
+//   * per head: q, k, v^T = W_h x^T (+ bias as the accumulators' initial value) with every weight fragment read from LDS once for the 4
+//     sequences, scores / softmax / PV in registers as in attention_h8_kernel, stage by stage over the 4 sequences (independent chains);
+//   * the PV accumulators of lane (token, q) are d = 4q..4q+3 and 16+4q..16+4q+3 of the head = one B fragment of the out-projection
+//     under a permutation of K that the LDS image of Wo carries too: the per-head output never leaves the registers and the 64 output
+//     channels accumulate over the heads in 16 accumulators per lane;
+//   * Wo's A-tile rows are permuted so that lane (token, q) ends up with 8 consecutive channels per 32-channel half: two 16-byte stores
+//     per sequence.
+// Waves drift apart freely, so one wave's loads / stores / softmax run under another's MFMAs.
+template <bool F8>
+__global__ __launch_bounds__(512) void attention_w_kernel(const AttnArgs P, const int groups_per_wave, const long ngroups) {
+    using M = Mma<MODE_BF16>;
+    constexpr int HD = 256, D = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Wq = smem;                                   // [768 rows][128 B]: 16-byte chunk c of row r at r * 128 + 16 * (c ^ (r & 7))
+    char* Wo = Wq + 3 * HD * 128;                      // [64 rows][512 B]: row R = 16 * tile + i holds channel 32 (tile >> 1) + 8 (i >> 2) + 4 (tile & 1) + (i & 3);
+                                                       // piece (head h, q) = d {4q..4q+3, 16+4q..16+4q+3} at 16 * ((4 h + q) ^ (R & 15))
+    float* bl = reinterpret_cast<float*>(Wo + 64 * 512);   // bqkv [768] | bo [64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lp = lane & 15, q = lane >> 4;
+
+    for (int i = tid; i < 3 * HD * 8; i += 512) {
+        const int r = i >> 3, c = i & 7;
+        *reinterpret_cast<uint4*>(Wq + r * 128 + 16 * (c ^ (r & 7))) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wqkv) + (size_t)r * 128 + c * 16);
+    }
+    for (int i = tid; i < 64 * 32; i += 512) {
+        const int R = i >> 5, c = i & 31, hh = c >> 2, qq = c & 3;
+        const int tile = R >> 4, ri = R & 15;
+        const int co = 32 * (tile >> 1) + 8 * (ri >> 2) + 4 * (tile & 1) + (ri & 3);
+        const char* src = reinterpret_cast<const char*>(P.wo) + (size_t)co * 512 + hh * 64 + qq * 8;
+        const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 32);
+        *reinterpret_cast<uint4*>(Wo + R * 512 + 16 * (c ^ (R & 15))) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    for (int i = tid; i < 3 * HD; i += 512) bl[i] = P.bqkv[i];
+    if (tid < 64) bl[3 * HD + tid] = P.bo[tid];
+    __syncthreads();                                   // the only barrier: weights visible
+
+    const long g_first = ((long)blockIdx.x * 8 + wave_u) * groups_per_wave;
+    const long g_end = g_first + groups_per_wave < ngroups ? g_first + groups_per_wave : ngroups;
+    if (g_first >= g_end) return;
+    const char* const xg = reinterpret_cast<const char*>(P.x);
+    char* const yg = reinterpret_cast<char*>(P.y);
+    // per-lane byte offset inside a group: sequence b adds b * inner_stride elements
+    const unsigned loff = (unsigned)(lp * P.tok_stride + q * 8) * 2u;
+    const unsigned sstr = (unsigned)P.inner_stride * 2u;
+    auto group_base = [&](long g) __attribute__((always_inline)) -> size_t {                       // wave-uniform: scalar unit
+        const unsigned inner = (unsigned)P.inner, sg0 = (unsigned)(g * 4);
+        return ((size_t)(sg0 / inner) * P.outer_stride + (size_t)(sg0 % inner) * P.inner_stride) * 2;
+    };
+    uint4 xn[4][2];
+    auto fetch = [&](long g) __attribute__((always_inline)) {
+        const char* p = xg + group_base(g) + loff;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) xn[b][ch] = *reinterpret_cast<const uint4*>(p + b * sstr + ch * 64);
+    };
+    const float escale = P.scale * 1.44269504088896f;
+    // LDS read offsets of this lane (head 0): q|k|v rows t * 16 + lp of a part, chunk ch * 4 + q; Wo rows tile * 16 + lp, piece 4 h + q
+    int wqo[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) wqo[ch] = lp * 128 + 16 * ((ch * 4 + q) ^ (lp & 7));            // (+ (part * 256 + h * 32 + t * 16) * 128: multiples of 8 rows)
+    const int woo = lp * 512;                          // + tile * 8192 + 16 * ((4 h + q) ^ lp)
+
+    fetch(g_first);
+    for (long g = g_first; g < g_end; ++g) {
+        uint4 xc[4][2];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { xc[b][0] = xn[b][0]; xc[b][1] = xn[b][1]; }
+        if (g + 1 < g_end) fetch(g + 1);
+        f32x4 oacc[4][4];                              // [sequence][tile = 2 wc + tm]
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bl + 3 * HD + 32 * (tile >> 1) + 8 * q + 4 * (tile & 1));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) oacc[b][tile] = f32x4{b4.x, b4.y, b4.z, b4.w};
+        }
+#pragma unroll 1
+        for (int h = 0; h < 8; ++h) {
+            const char* wh = Wq + h * (D * 128);
+            f32x4 aq[4][2], ak[4][2];
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                f32x4 (&acc)[4][2] = part == 0 ? aq : ak;
+                uint4 wf[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(bl + part * HD + h * D + t * 16 + 4 * q);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[b][t] = f32x4{b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) wf[ch][t] = *reinterpret_cast<const uint4*>(wh + (part * HD + t * 16) * 128 + wqo[ch]);
+                }
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) M::mma(acc[b][t], wf[ch][t], xc[b][ch]);
+            }
+            f32x4 sc[4];                               // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                sc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+                core_mma16<M, F8>(sc[b], ak[b][0], aq[b][0]);
+                core_mma16<M, F8>(sc[b], ak[b][1], aq[b][1]);
+            }
+            // v projection (rows = tokens, cols = d) issued before the softmax: its MFMAs run under the softmax's VALU work
+            f32x4 av[4][2];
+            {
+                uint4 wf[2][2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float c = bl[2 * HD + h * D + t * 16 + lp];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) av[b][t] = f32x4{c, c, c, c};
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) wf[ch][t] = *reinterpret_cast<const uint4*>(wh + (2 * HD + t * 16) * 128 + wqo[ch]);
+                }
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) M::mma(av[b][t], xc[b][ch], wf[ch][t]);
+            }
+            float mx[4], sum[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mx[b] = fmaxf(fmaxf(sc[b][0], sc[b][1]), fmaxf(sc[b][2], sc[b][3]));
+#pragma unroll
+            for (int b = 0; b < 4; ++b) mx[b] = max_q(mx[b]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float nmx = -mx[b] * escale;     // exp2((s - max) * k) = exp2(fma(s, k, -max * k)): one FMA per score
+                sum[b] = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[b][r] = __builtin_amdgcn_exp2f(fmaf(sc[b][r], escale, nmx)); sum[b] += sc[b][r]; }
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b) sum[b] = reduce_q(sum[b]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float inv = __builtin_amdgcn_rcpf(sum[b]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[b][r] *= inv;
+            }
+            uint4 of[4];                               // O_h^T as the out-projection's B fragment (K slots in accumulator order)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                f32x4 o[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    core_mma16<M, F8>(o[t], av[b][t], sc[b]);
+                }
+                of[b] = make_uint4(pack_bf16x2(o[0][0], o[0][1]), pack_bf16x2(o[0][2], o[0][3]), pack_bf16x2(o[1][0], o[1][1]), pack_bf16x2(o[1][2], o[1][3]));
+            }
+            const char* woh = Wo + woo + 16 * ((4 * h + q) ^ lp);
+#pragma unroll
+            for (int tile = 0; tile < 4; ++tile) {
+                const uint4 wof = *reinterpret_cast<const uint4*>(woh + tile * 8192);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) M::mma(oacc[b][tile], wof, of[b]);
+            }
+        }
+        // + residual (the fetched rows), two 16-byte stores per sequence
+        char* yp = yg + group_base(g) + loff;
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int wc = 0; wc < 2; ++wc) {
+                const uint4 r = xc[b][wc];
+                const f32x4 a0 = oacc[b][2 * wc], a1 = oacc[b][2 * wc + 1];
+                uint4 w;
+                w.x = pack_bf16x2(a0[0] + __uint_as_float(r.x << 16), a0[1] + __uint_as_float(r.x & 0xFFFF0000u));
+                w.y = pack_bf16x2(a0[2] + __uint_as_float(r.y << 16), a0[3] + __uint_as_float(r.y & 0xFFFF0000u));
+                w.z = pack_bf16x2(a1[0] + __uint_as_float(r.z << 16), a1[1] + __uint_as_float(r.z & 0xFFFF0000u));
+                w.w = pack_bf16x2(a1[2] + __uint_as_float(r.w << 16), a1[3] + __uint_as_float(r.w & 0xFFFF0000u));
+                *reinterpret_cast<uint4*>(yp + b * sstr + wc * 64) = w;
+            }
+    }
+}
+
+#ifndef VDX_ATTN_W
+#define VDX_ATTN_W 1
+#endif
+static bool attn_w_eligible(const AttnArgs& a) {
+    return VDX_ATTN_W && a.io_bf16 && a.C == 64 && a.CPad == 64 && a.HDPad == 256 && a.heads == 8 && a.L == 16 && a.inner % 4 == 0 && a.nseq % 4 == 0 &&
+           a.nseq >= 256 && a.nseq < (1L << 29) && 3 * a.inner_stride + 15 * a.tok_stride + a.C < (1L << 30);
+}
+template <bool F8>
+static hipError_t launch_attn_w(const AttnArgs& a, hipStream_t st) {
+    const size_t lds = 3 * 256 * 128 + 64 * 512 + (3 * 256 + 64) * 4;
+    auto kfn = attention_w_kernel<F8>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const long ngroups = a.nseq / 4;
+    const long waves = std::min<long>((long)cus * 8, ngroups);
+    const int gpw = (int)((ngroups + waves - 1) / waves);
+    const long blocks = (ngroups + (long)gpw * 8 - 1) / ((long)gpw * 8);
+    const AttnWork aw = attn_work(a, 2, true);
+    LaunchScope ls(st, "attention_w_kernel", aw.flops, aw.bytes, "<fp8 %d> C%d L%d nseq%ld", (int)F8, a.C, a.L, a.nseq);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, st, a, gpw, ngroups);
+    return hipGetLastError();
+}
+
 // ---- wide levels (C >= 256): one workgroup per (head, sequence chunk) ----------------------------------------------------------------
 // The per-head q/k/v weights (96 rows x C bf16, up to 99 KB) are loaded into LDS ONCE per workgroup instead of once per 64 rows;
 // every wave then walks its own sequences with no workgroup barrier: x fragments (16 tokens x 32 channels) come straight from
@@ -990,6 +1206,7 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
                 if (a.C == 64 && nkt == 1) return launch_attn_h8_t<MODE, 1, 1, 2, false, true>(a, st);
                 if (a.C == 128 && nkt == 2) return launch_attn_h8_t<MODE, 2, 1, 4, false, true>(a, st);
             }
+            if (attn_w_eligible(a)) return launch_attn_w<false>(a, st);                       // level 0: one wave per group of 4 sequences
             if (a.io_bf16 && a.C == 64 && a.L == 16) return launch_attn_h8_t<MODE, 1, 1, 2, true, false, true>(a, st);
             if (a.io_bf16 && a.C == 128 && a.L == 16) return launch_attn_h8_t<MODE, 2, 1, 4, true, false, true>(a, st);
             if (a.io_bf16 && a.C == 64) return launch_attn_h8_t<MODE, 1, 1, 2, true>(a, st);

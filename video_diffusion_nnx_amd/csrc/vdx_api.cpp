@@ -224,6 +224,28 @@ int vdx_attention_forward_ex(int mode, const float* x, float* y, const void* wqk
     return VDX_OK;
 }
 
+int vdx_attention_forward_bf16(const void* x_bf16, void* y_bf16, const void* wqkv_packed, const float* bqkv,
+                               const void* wo_packed, const float* bo, int batch, int frames, int h, int w, int c, int heads,
+                               int temporal, int fp8_core, void* stream) {
+    if (!x_bf16 || !y_bf16 || !wqkv_packed || !bqkv || !wo_packed || !bo) VDX_FAIL(VDX_ERR_INVALID, "attention: null tensor");
+    if (c % 8 || c > 1024 || heads < 1) VDX_FAIL(VDX_ERR_INVALID, "attention (bf16 tensors): C must be a multiple of 8 and <= 1024");
+    vdx::AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = reinterpret_cast<const float*>(x_bf16); a.y = reinterpret_cast<float*>(y_bf16); a.io_bf16 = 1;
+    a.wqkv = wqkv_packed; a.bqkv = bqkv; a.wo = wo_packed; a.bo = bo; a.C = c; a.heads = heads;
+    a.scale = 1.0f / sqrtf(32.0f);
+    const long hw = (long)h * w;
+    if (temporal) {
+        a.L = frames; a.nseq = (long)batch * hw; a.inner = hw; a.inner_stride = c; a.outer_stride = (long)frames * hw * c; a.tok_stride = hw * c;
+    } else {
+        a.L = (int)hw; a.nseq = (long)batch * frames; a.inner = 1; a.inner_stride = 0; a.outer_stride = hw * c; a.tok_stride = c;
+    }
+    if (a.L > 64) VDX_FAIL(VDX_ERR_INVALID, "attention: more than 64 tokens per sequence is not supported");
+    a.fp8_core = fp8_core ? 1 : 0;
+    VDX_HIP(vdx::launch_attention(VDX_MODE_BF16, a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
 size_t vdx_sla_workspace_bytes(int mode, int nframes, int npix, int heads) { return vdx::sla_workspace_bytes(mode, nframes, npix, heads); }
 
 int vdx_sla_forward(int mode, const float* x, float* y, const void* wq_packed, const void* wk_packed, const void* wv_packed,

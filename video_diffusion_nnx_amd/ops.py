@@ -132,6 +132,17 @@ def attention_forward(x, packed, heads, temporal, mode, fp8_core=False):
     return y
 
 
+def attention_forward_bf16(x, packed, heads, temporal, fp8_core=False):
+    """x: bf16 channel-last [B, F, H, W, C]; packed = pack_mha(..., 'bf16')."""
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    B, Fr, H, W, C_ = x.shape
+    y = torch.empty_like(x)
+    wqkv, bqkv, wo, bo = packed
+    L.check(L.vdx_attention_forward_bf16(L.ptr(x), L.ptr(y), L.ptr(wqkv), L.ptr(bqkv), L.ptr(wo), L.ptr(bo),
+                                         B, Fr, H, W, C_, heads, int(temporal), int(bool(fp8_core)), L.stream_ptr()))
+    return y
+
+
 def sla_forward(x, wq, wk, wv, wo, heads, mode):
     """wq/wk/wv: Flax (1, C, 256); wo: (1, 256, C)."""
     B, Fr, H, W, C_ = x.shape
