@@ -137,6 +137,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-y-shape', action='store_true', help='skip the secondary timing of the YAML-literal config_v2_2 (dim 32, 10 frames)')
+    ap.add_argument('--no-other-configs', action='store_true', help='skip the secondary timings of BASELINE.json configs[3] (dim 128, 32f x 128 x 128, DDIM, fp16 operands) and configs[4] (text-conditioned, classifier-free guidance, fp8 attention)')
     ap.add_argument('--launch-seq', default='', help='write the (kernel, shape, flops, bytes) sequence of one denoising step to this JSON file (tools/shape_table.py joins it with a rocprofv3 kernel trace)')
     ap.add_argument('--no-train', action='store_true', help='skip the training leg (p_losses fwd+bwd, bucketed all-reduce, Adam/EMA)')
     ap.add_argument('--comm', default=os.environ.get('VDX_COMM', 'torch'), choices=['torch', 'abi'], help="gradient all-reduce of the training leg: torch.distributed (RCCL under 'nccl') or the communicator behind the C ABI (vdx_allreduce_bucket)")
@@ -270,6 +271,61 @@ def sampling_leg(args, dev, world, rank, dim, Fr, S, B, steps, warmup, roofline)
     return elapsed / steps * 1e3, act, rec
 
 
+def other_configs_leg(dev, world):
+    """Secondary timings of the two BASELINE.json configurations that have no reference code (DDIM / fp16 / fp8 are extensions of this
+    build, parity unpinned): per-step time of the captured loops through the public Python surface, as the difference of a long and
+    a short chain (capture and first-touch costs cancel).  This rank only; no roofline claim -- these shapes run on the generic
+    kernels in fp16 mode."""
+    import torch
+    from video_diffusion_nnx_amd.gaussian_diffusion import GaussianDiffusion
+    from video_diffusion_nnx_amd.unet3d import Unet3D
+
+    def timed(fn):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize(dev)
+        assert torch.isfinite(out).all()
+        return time.perf_counter() - t0
+
+    res = {}
+    # configs[3]: dim 128, C = 3, 32 frames of 128 x 128, DDIM (100 steps in the config; 2 and 6 timed), fp16 operands (fp32 tensors)
+    for mode in ('f16', 'bf16'):
+        B, Fr, S, C = 1, 32, 128, 3
+        unet = Unet3D(dim=128, rngs=0, channels=C, mode=mode, device=dev)
+        gd = GaussianDiffusion(unet, image_size=S, num_frames=Fr, channels=C, timesteps=T_STEPS)
+        gd.ddim_sample_loop((B, C, Fr, S, S), 1, steps=2)                      # warm-up: packing, workspace, capture
+        t2 = timed(lambda: gd.ddim_sample_loop((B, C, Fr, S, S), 1, steps=2))
+        t6 = timed(lambda: gd.ddim_sample_loop((B, C, Fr, S, S), 1, steps=6))
+        ms = (t6 - t2) / 4 * 1e3
+        res[f'configs3_{mode}'] = {'workload': f'dim=128 C=3 {Fr}f x {S}x{S}, DDIM eta=0 (100-step chain = 100 x this step), {mode} MFMA operands, '
+                                               + ('bf16 activation storage' if mode == 'bf16' else 'fp32 tensors'),
+                                   'batch_per_gpu': B, 'ms_per_step': ms, 'frames_per_s_ddim100': world * B * Fr / (100 * ms * 1e-3),
+                                   'tflops': B * 6707.9e9 / (ms * 1e-3) / 1e12}
+        log(f"configs[3] {mode}: {ms:.2f} ms/step at B = {B}")
+        del unet, gd
+        torch.cuda.empty_cache()
+    # configs[4]: text-conditioned (cond_dim 768) 16f x 64 x 64, classifier-free guidance (one 2B-batched forward per step), fp8 QK^T / PV
+    for fp8 in (True, False):
+        B, Fr, S = 32, 16, 64
+        unet = Unet3D(dim=64, rngs=0, channels=1, cond_dim=768, mode='bf16', device=dev, attn_fp8=fp8)
+        cond = torch.randn(B, 768, device=dev)
+        ts = {}
+        for T in (2, 6):
+            gd = GaussianDiffusion(unet, image_size=S, num_frames=Fr, channels=1, timesteps=T)
+            gd.p_sample_loop((B, 1, Fr, S, S), 1, cond=cond, cond_scale=2.0)
+            ts[T] = timed(lambda: gd.p_sample_loop((B, 1, Fr, S, S), 1, cond=cond, cond_scale=2.0))
+        ms = (ts[6] - ts[2]) / 4 * 1e3
+        res['configs4_fp8attn' if fp8 else 'configs4_bf16attn'] = {
+            'workload': f'dim=64 C=1 cond_dim=768 {Fr}f x {S}x{S}, DDPM step with classifier-free guidance (cond_scale 2: 2B forwards per step), '
+                        + ('fp8 e4m3 QK^T / PV' if fp8 else 'bf16 QK^T / PV'), 'batch_per_gpu': B, 'ms_per_step': ms,
+            'frames_per_s_ddpm1000': world * B * Fr / (T_STEPS * ms * 1e-3)}
+        log(f"configs[4] fp8 attention {fp8}: {ms:.2f} ms/step at B = {B} (2B forwards)")
+        del unet, gd, cond
+        torch.cuda.empty_cache()
+    return res
+
+
 def kernel_row(key, d, mode, ms_per_step):
     """One (kernel, shape) entry of the roofline table: both fractions, and which roofline binds by arithmetic intensity."""
     mfma_peak = MFMA_PEAK_TFLOPS[mode]
@@ -328,6 +384,8 @@ def main():
                            'ms_per_step': yms, 'frames_per_s': world * B * 10 / (T_STEPS * yms * 1e-3),
                            'tflops': world * B * 54.09e9 / (yms * 1e-3) / 1e12, 'n_shape_tflops': world * B * 250.77e9 / (ms_per_step * 1e-3) / 1e12}
         log(f"Y shape: {yms:.3f} ms/step, {line['y_shape']['frames_per_s']:.1f} frames/s")
+    if rank == 0 and not args.no_other_configs:
+        line['other_configs'] = other_configs_leg(dev, world)
     if not args.no_train:
         log('training leg (p_losses fwd+bwd + bucketed all-reduce + Adam/EMA) ...')
         line['train'] = train_leg(args, dev, world, rank)         # every rank takes part (collectives inside)

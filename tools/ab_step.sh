@@ -7,7 +7,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 for v in "$@"; do
   lib=$root/video_diffusion_nnx_amd/variants/libvdx_$v.so
   [ "$v" = product ] && lib=$root/video_diffusion_nnx_amd/libvdx.so
-  VDX_LIB=$lib python3 "$root/bench.py" --no-cpu-baseline --no-train --no-y-shape --steps 12 --warmup 3 > "$root/gpurun_out/ab_$v.json" 2> "$root/gpurun_out/ab_$v.log" || { echo "$v FAILED"; tail -3 "$root/gpurun_out/ab_$v.log"; continue; }
+  VDX_LIB=$lib python3 "$root/bench.py" --no-cpu-baseline --no-train --no-y-shape --no-other-configs --steps 12 --warmup 3 > "$root/gpurun_out/ab_$v.json" 2> "$root/gpurun_out/ab_$v.log" || { echo "$v FAILED"; tail -3 "$root/gpurun_out/ab_$v.log"; continue; }
   python3 - "$root/gpurun_out/ab_$v.json" "$pat" "$v" <<'PY'
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])

@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_step_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 "$root/bench.py" --no-cpu-baseline --no-train --no-y-shape --steps 20 --warmup 3 \
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out" -- python3 "$root/bench.py" --no-cpu-baseline --no-train --no-y-shape --no-other-configs --steps 20 --warmup 3 \
     --launch-seq "$out/seq.json" "$@" > "$out/bench.json" 2> "$out/bench.log"
 cp "$out"/*/*kernel_stats.csv "$out/kernel_stats.csv"
 python3 "$root/tools/shape_table.py" "$out" "$out/seq.json" --skip-steps 2 --take 20 --md > "$out/shape_table.md"

@@ -10,8 +10,8 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/traffic_$name
 rm -rf "$out"; mkdir -p "$out/f" "$out/w"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/f" -- python3 "$root/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-train --no-y-shape "$@" > "$out/f/log.txt" 2>&1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/f" -- python3 "$root/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-train --no-y-shape --no-other-configs "$@" > "$out/f/log.txt" 2>&1
 echo "fetch pass done" >> "$out/progress.txt"
-timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/w" -- python3 "$root/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-train --no-y-shape "$@" > "$out/w/log.txt" 2>&1
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/w" -- python3 "$root/bench.py" --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-train --no-y-shape --no-other-configs "$@" > "$out/w/log.txt" 2>&1
 echo "write pass done" >> "$out/progress.txt"
 python3 "$root/tools/shape_table.py" "$out" "$seq" --traffic "$root/gpurun_out/$name.json" "$out/f" "$out/w"

@@ -780,10 +780,30 @@ static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
 //   * Wo's A-tile rows are permuted so that lane (token, q) ends up with 8 consecutive channels per 32-channel half: two 16-byte stores
 //     per sequence.
 // Waves drift apart freely, so one wave's loads / stores / softmax run under another's MFMAs.
+// Measured at level 0 of the N shape (B = 64; attention_h8_kernel on the same boxes: 735-756 us): stages in the compiler's order 654-689 us;
+// with every stage's weight fragments read one stage ahead and the 8 PV products issued before their packing (this form) 608-627; +
+// a start skew between the two waves of a SIMD and s_setprio over the projection blocks 598-611.  Counters (r03): MFMA busy ~51 %, 45 % of
+// wave life issue-stalled, 13 % parked.  Built on the same body and NOT faster: 2 sequences per wave with 12 waves (3 per SIMD, 144
+// registers) 637, with 16 waves (128 registers, 68 B scratch) 668; the head loop rotated so that the q / k projections of head h + 1
+// are issued in front of the softmax of head h (needs 2 sequences per wave to fit: 210 registers) 723 -- the SIMD's vector issue port
+// (an MFMA holds it 8 of its 16 cycles, every VALU op 4, transcendentals 8: ~1800 cycles per head and 4 sequences against 1152 of
+// matrix pipe) is what bounds it, not latency: more waves or more overlap inside a wave add issue work (LDS reads per MFMA double).
+#ifndef VDX_AW_SKEW
+#define VDX_AW_SKEW 40        // s_sleep units (64 cycles) the second wave of a SIMD starts late: the two leave the barrier in the same phase (0: 618-622 us, 16: 625, 40: 598)
+#endif
+#ifndef VDX_AW_PRIO
+#define VDX_AW_PRIO 1          // s_setprio 1 over the projection MFMA blocks (611 vs 618-622 us)
+#endif
+#ifndef VDX_AW_SB
+#define VDX_AW_SB 4           // sequences per wave and group (4: a token's 4 x 128 bytes are one run; 2: half the registers, twice the weight reads per MFMA)
+#endif
+#ifndef VDX_AW_NW
+#define VDX_AW_NW 8           // waves per workgroup (8 = 2 per SIMD at <= 256 registers, 12 = 3 at <= 168)
+#endif
 template <bool F8>
-__global__ __launch_bounds__(512) void attention_w_kernel(const AttnArgs P, const int groups_per_wave, const long ngroups) {
+__global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnArgs P, const int groups_per_wave, const long ngroups) {
     using M = Mma<MODE_BF16>;
-    constexpr int HD = 256, D = 32;
+    constexpr int HD = 256, D = 32, SB = VDX_AW_SB, NT = 64 * VDX_AW_NW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Wq = smem;                                   // [768 rows][128 B]: 16-byte chunk c of row r at r * 128 + 16 * (c ^ (r & 7))
     char* Wo = Wq + 3 * HD * 128;                      // [64 rows][512 B]: row R = 16 * tile + i holds channel 32 (tile >> 1) + 8 (i >> 2) + 4 (tile & 1) + (i & 3);
@@ -793,11 +813,11 @@ __global__ __launch_bounds__(512) void attention_w_kernel(const AttnArgs P, cons
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 15, q = lane >> 4;
 
-    for (int i = tid; i < 3 * HD * 8; i += 512) {
+    for (int i = tid; i < 3 * HD * 8; i += NT) {
         const int r = i >> 3, c = i & 7;
         *reinterpret_cast<uint4*>(Wq + r * 128 + 16 * (c ^ (r & 7))) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wqkv) + (size_t)r * 128 + c * 16);
     }
-    for (int i = tid; i < 64 * 32; i += 512) {
+    for (int i = tid; i < 64 * 32; i += NT) {
         const int R = i >> 5, c = i & 31, hh = c >> 2, qq = c & 3;
         const int tile = R >> 4, ri = R & 15;
         const int co = 32 * (tile >> 1) + 8 * (ri >> 2) + 4 * (tile & 1) + (ri & 3);
@@ -805,27 +825,33 @@ __global__ __launch_bounds__(512) void attention_w_kernel(const AttnArgs P, cons
         const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 32);
         *reinterpret_cast<uint4*>(Wo + R * 512 + 16 * (c ^ (R & 15))) = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
-    for (int i = tid; i < 3 * HD; i += 512) bl[i] = P.bqkv[i];
+    for (int i = tid; i < 3 * HD; i += NT) bl[i] = P.bqkv[i];
     if (tid < 64) bl[3 * HD + tid] = P.bo[tid];
     __syncthreads();                                   // the only barrier: weights visible
 
-    const long g_first = ((long)blockIdx.x * 8 + wave_u) * groups_per_wave;
+    const long g_first = ((long)blockIdx.x * VDX_AW_NW + wave_u) * groups_per_wave;
     const long g_end = g_first + groups_per_wave < ngroups ? g_first + groups_per_wave : ngroups;
     if (g_first >= g_end) return;
+#if VDX_AW_SKEW
+    // the two waves of a SIMD (w, w + 4) leave the barrier in the same phase and would issue their MFMA-heavy and their VALU-heavy stages
+    // at the same time: the second one starts half a head iteration late
+    if (wave_u >= 4) __builtin_amdgcn_s_sleep(VDX_AW_SKEW);
+    if (wave_u >= 8) __builtin_amdgcn_s_sleep(VDX_AW_SKEW);
+#endif
     const char* const xg = reinterpret_cast<const char*>(P.x);
     char* const yg = reinterpret_cast<char*>(P.y);
     // per-lane byte offset inside a group: sequence b adds b * inner_stride elements
     const unsigned loff = (unsigned)(lp * P.tok_stride + q * 8) * 2u;
     const unsigned sstr = (unsigned)P.inner_stride * 2u;
     auto group_base = [&](long g) __attribute__((always_inline)) -> size_t {                       // wave-uniform: scalar unit
-        const unsigned inner = (unsigned)P.inner, sg0 = (unsigned)(g * 4);
+        const unsigned inner = (unsigned)P.inner, sg0 = (unsigned)(g * SB);
         return ((size_t)(sg0 / inner) * P.outer_stride + (size_t)(sg0 % inner) * P.inner_stride) * 2;
     };
-    uint4 xn[4][2];
+    uint4 xn[SB][2];
     auto fetch = [&](long g) __attribute__((always_inline)) {
         const char* p = xg + group_base(g) + loff;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < SB; ++b)
 #pragma unroll
             for (int ch = 0; ch < 2; ++ch) xn[b][ch] = *reinterpret_cast<const uint4*>(p + b * sstr + ch * 64);
     };
@@ -836,111 +862,140 @@ __global__ __launch_bounds__(512) void attention_w_kernel(const AttnArgs P, cons
     for (int ch = 0; ch < 2; ++ch) wqo[ch] = lp * 128 + 16 * ((ch * 4 + q) ^ (lp & 7));            // (+ (part * 256 + h * 32 + t * 16) * 128: multiples of 8 rows)
     const int woo = lp * 512;                          // + tile * 8192 + 16 * ((4 h + q) ^ lp)
 
+    uint4 wcur[2][2], wnext[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) wcur[ch][t] = *reinterpret_cast<const uint4*>(Wq + t * 16 * 128 + wqo[ch]);
     fetch(g_first);
     for (long g = g_first; g < g_end; ++g) {
-        uint4 xc[4][2];
+        uint4 xc[SB][2];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { xc[b][0] = xn[b][0]; xc[b][1] = xn[b][1]; }
+        for (int b = 0; b < SB; ++b) { xc[b][0] = xn[b][0]; xc[b][1] = xn[b][1]; }
         if (g + 1 < g_end) fetch(g + 1);
-        f32x4 oacc[4][4];                              // [sequence][tile = 2 wc + tm]
+        f32x4 oacc[SB][4];                              // [sequence][tile = 2 wc + tm]
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile) {
             const float4 b4 = *reinterpret_cast<const float4*>(bl + 3 * HD + 32 * (tile >> 1) + 8 * q + 4 * (tile & 1));
 #pragma unroll
-            for (int b = 0; b < 4; ++b) oacc[b][tile] = f32x4{b4.x, b4.y, b4.z, b4.w};
+            for (int b = 0; b < SB; ++b) oacc[b][tile] = f32x4{b4.x, b4.y, b4.z, b4.w};
         }
+        // weight fragments one stage ahead: the reads of the next stage's fragments are issued in front of the current stage's MFMAs
+        // (every stage otherwise starts with an exposed LDS round trip), the PV products of the 4 sequences before their packing
 #pragma unroll 1
         for (int h = 0; h < 8; ++h) {
             const char* wh = Wq + h * (D * 128);
-            f32x4 aq[4][2], ak[4][2];
+            auto rd = [&](uint4 (&w)[2][2], const char* base) __attribute__((always_inline)) {
 #pragma unroll
-            for (int part = 0; part < 2; ++part) {
-                f32x4 (&acc)[4][2] = part == 0 ? aq : ak;
-                uint4 wf[2][2];
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(bl + part * HD + h * D + t * 16 + 4 * q);
+                    for (int ch = 0; ch < 2; ++ch) w[ch][t] = *reinterpret_cast<const uint4*>(base + t * 16 * 128 + wqo[ch]);
+            };
+            f32x4 aq[SB][2], ak[SB][2], av[SB][2];
+            // q (fragments in wcur)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) acc[b][t] = f32x4{b4.x, b4.y, b4.z, b4.w};
+            for (int t = 0; t < 2; ++t) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bl + h * D + t * 16 + 4 * q);
 #pragma unroll
-                    for (int ch = 0; ch < 2; ++ch) wf[ch][t] = *reinterpret_cast<const uint4*>(wh + (part * HD + t * 16) * 128 + wqo[ch]);
-                }
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) M::mma(acc[b][t], wf[ch][t], xc[b][ch]);
+                for (int b = 0; b < SB; ++b) aq[b][t] = f32x4{b4.x, b4.y, b4.z, b4.w};
             }
-            f32x4 sc[4];                               // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
+            rd(wnext, wh + HD * 128);
+            __builtin_amdgcn_sched_barrier(0);
+            if (VDX_AW_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int b = 0; b < SB; ++b) M::mma(aq[b][t], wcur[ch][t], xc[b][ch]);
+            // k (fragments in wnext)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bl + HD + h * D + t * 16 + 4 * q);
+#pragma unroll
+                for (int b = 0; b < SB; ++b) ak[b][t] = f32x4{b4.x, b4.y, b4.z, b4.w};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            rd(wcur, wh + 2 * HD * 128);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int b = 0; b < SB; ++b) M::mma(ak[b][t], wnext[ch][t], xc[b][ch]);
+            f32x4 sc[SB];
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
                 sc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
                 core_mma16<M, F8>(sc[b], ak[b][0], aq[b][0]);
                 core_mma16<M, F8>(sc[b], ak[b][1], aq[b][1]);
             }
-            // v projection (rows = tokens, cols = d) issued before the softmax: its MFMAs run under the softmax's VALU work
-            f32x4 av[4][2];
-            {
-                uint4 wf[2][2];
+            // v (fragments in wcur); the out-projection's fragments go to wnext
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float c = bl[2 * HD + h * D + t * 16 + lp];
+            for (int t = 0; t < 2; ++t) {
+                const float c = bl[2 * HD + h * D + t * 16 + lp];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) av[b][t] = f32x4{c, c, c, c};
-#pragma unroll
-                    for (int ch = 0; ch < 2; ++ch) wf[ch][t] = *reinterpret_cast<const uint4*>(wh + (2 * HD + t * 16) * 128 + wqo[ch]);
-                }
-#pragma unroll
-                for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) M::mma(av[b][t], xc[b][ch], wf[ch][t]);
+                for (int b = 0; b < SB; ++b) av[b][t] = f32x4{c, c, c, c};
             }
-            float mx[4], sum[4];
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const char* woh = Wo + woo + 16 * ((4 * h + q) ^ lp);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) mx[b] = fmaxf(fmaxf(sc[b][0], sc[b][1]), fmaxf(sc[b][2], sc[b][3]));
+                for (int tile = 0; tile < 4; ++tile) wnext[tile >> 1][tile & 1] = *reinterpret_cast<const uint4*>(woh + tile * 8192);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) mx[b] = max_q(mx[b]);
+            for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const float nmx = -mx[b] * escale;     // exp2((s - max) * k) = exp2(fma(s, k, -max * k)): one FMA per score
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int b = 0; b < SB; ++b) M::mma(av[b][t], xc[b][ch], wcur[ch][t]);
+            if (VDX_AW_PRIO) __builtin_amdgcn_s_setprio(0);
+            float mx[SB], sum[SB];
+#pragma unroll
+            for (int b = 0; b < SB; ++b) mx[b] = fmaxf(fmaxf(sc[b][0], sc[b][1]), fmaxf(sc[b][2], sc[b][3]));
+#pragma unroll
+            for (int b = 0; b < SB; ++b) mx[b] = max_q(mx[b]);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                const float nmx = -mx[b] * escale;
                 sum[b] = 0.f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { sc[b][r] = __builtin_amdgcn_exp2f(fmaf(sc[b][r], escale, nmx)); sum[b] += sc[b][r]; }
             }
 #pragma unroll
-            for (int b = 0; b < 4; ++b) sum[b] = reduce_q(sum[b]);
+            for (int b = 0; b < SB; ++b) sum[b] = reduce_q(sum[b]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
+            for (int b = 0; b < SB; ++b) {
                 const float inv = __builtin_amdgcn_rcpf(sum[b]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) sc[b][r] *= inv;
             }
-            uint4 of[4];                               // O_h^T as the out-projection's B fragment (K slots in accumulator order)
+            __builtin_amdgcn_sched_barrier(0);
+            rd(wcur, Wq + ((h + 1) & 7) * (D * 128));   // the next head's q fragments (head 0 of the next group after head 7)
+            f32x4 o[SB][2];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                f32x4 o[2];
+            for (int b = 0; b < SB; ++b)
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    core_mma16<M, F8>(o[t], av[b][t], sc[b]);
+                    o[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    core_mma16<M, F8>(o[b][t], av[b][t], sc[b]);
                 }
-                of[b] = make_uint4(pack_bf16x2(o[0][0], o[0][1]), pack_bf16x2(o[0][2], o[0][3]), pack_bf16x2(o[1][0], o[1][1]), pack_bf16x2(o[1][2], o[1][3]));
-            }
-            const char* woh = Wo + woo + 16 * ((4 * h + q) ^ lp);
+            __builtin_amdgcn_sched_barrier(0);
+            uint4 of[SB];
 #pragma unroll
-            for (int tile = 0; tile < 4; ++tile) {
-                const uint4 wof = *reinterpret_cast<const uint4*>(woh + tile * 8192);
+            for (int b = 0; b < SB; ++b)
+                of[b] = make_uint4(pack_bf16x2(o[b][0][0], o[b][0][1]), pack_bf16x2(o[b][0][2], o[b][0][3]), pack_bf16x2(o[b][1][0], o[b][1][1]), pack_bf16x2(o[b][1][2], o[b][1][3]));
 #pragma unroll
-                for (int b = 0; b < 4; ++b) M::mma(oacc[b][tile], wof, of[b]);
-            }
+            for (int tile = 0; tile < 4; ++tile)
+#pragma unroll
+                for (int b = 0; b < SB; ++b) M::mma(oacc[b][tile], wnext[tile >> 1][tile & 1], of[b]);
         }
         // + residual (the fetched rows), two 16-byte stores per sequence
         char* yp = yg + group_base(g) + loff;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < SB; ++b)
 #pragma unroll
             for (int wc = 0; wc < 2; ++wc) {
                 const uint4 r = xc[b][wc];
@@ -970,13 +1025,13 @@ static hipError_t launch_attn_w(const AttnArgs& a, hipStream_t st) {
     if (e != hipSuccess) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
-    const long ngroups = a.nseq / 4;
-    const long waves = std::min<long>((long)cus * 8, ngroups);
+    const long ngroups = a.nseq / VDX_AW_SB;
+    const long waves = std::min<long>((long)cus * VDX_AW_NW, ngroups);
     const int gpw = (int)((ngroups + waves - 1) / waves);
-    const long blocks = (ngroups + (long)gpw * 8 - 1) / ((long)gpw * 8);
+    const long blocks = (ngroups + (long)gpw * VDX_AW_NW - 1) / ((long)gpw * VDX_AW_NW);
     const AttnWork aw = attn_work(a, 2, true);
     LaunchScope ls(st, "attention_w_kernel", aw.flops, aw.bytes, "<fp8 %d> C%d L%d nseq%ld", (int)F8, a.C, a.L, a.nseq);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(512), lds, st, a, gpw, ngroups);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(64 * VDX_AW_NW), lds, st, a, gpw, ngroups);
     return hipGetLastError();
 }
 
@@ -985,13 +1040,17 @@ static hipError_t launch_attn_w(const AttnArgs& a, hipStream_t st) {
 // every wave then walks its own sequences with no workgroup barrier: x fragments (16 tokens x 32 channels) come straight from
 // global memory / L2 (each x row is read by the 8 head-workgroups), weight fragments from LDS, and the core runs in registers as in
 // attention_reg_kernel.  Output: O[row][head*32 + d] bf16; the out-projection (+bias, +residual) is a plain 1x1 conv_igemm.
-template <bool IO16, int TT, bool F8>
+template <bool IO16, int TT, bool F8, int LT = 1>
 __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, const int seq_per_block, const int nchunks) {
-    // TT sequences per wave at a time: each weight fragment read from LDS feeds TT MFMAs (one sequence per read would make the kernel
+    // TT 16-token tiles per wave at a time: each weight fragment read from LDS feeds TT MFMAs (one tile per read would make the kernel
     // LDS-bandwidth bound: 6 KB of fragments per 6 MFMAs per wave), and the x fragments run through a 4-deep register ring so that
-    // global loads are issued four K steps ahead of their use.
+    // global loads are issued four K steps ahead of their use.  LT = tiles per sequence: 1 = sequences of <= 16 tokens (TT sequences per
+    // group), 4 = sequences of <= 64 tokens (the mid block's spatial attention over 8 x 8 pixels; round 3: that launch was the LDS-staged
+    // attention_kernel, which re-stages the 786 KB of q|k|v weights for every 64 rows: 367 us at 0.08 of the MFMA peak): the scores of
+    // a query tile run over the LT key tiles of its sequence, the softmax over 16 LT keys is in-lane + the two quad swaps.
     using M = Mma<MODE_BF16>;
-    constexpr int D = 32;
+    constexpr int D = 32, NS = TT / LT;                               // sequences per group
+    static_assert(TT % LT == 0, "whole sequences per group");
     extern __shared__ __attribute__((aligned(16))) char smem[];      // W_h [96 rows][C * 2 + 32]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int lp = lane & 15, q = lane >> 4;
@@ -1016,24 +1075,23 @@ __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, c
         bq[t] = f32x4{a.x, a.y, a.z, a.w}; bk[t] = f32x4{b.x, b.y, b.z, b.w}; bv[t] = f32x4{c, c, c, c};
     }
     const float escale = P.scale * 1.44269504088896f;
-    const bool masked = P.L < 16;
+    const bool masked = P.L < 16 * LT;
     __syncthreads();
     const int s0 = chunk_id * seq_per_block;
     const int send = min((int)P.nseq, s0 + seq_per_block);
     const int nkt = P.C / 32;                                         // multiple of 4 (launcher)
     const char* wrow = smem + lp * RSW + q * 16;
-    const bool tv = lp < P.L;
     const int inner = (int)P.inner;
 
-    // fetch side: group of TT sequences starting at fs, K step fk
-    int fs = s0 + w * TT, fk = 0;
+    // fetch side: group of NS sequences starting at fs, K step fk; tile tt = token tile tt % LT of sequence fs + tt / LT
+    int fs = s0 + w * NS, fk = 0;
     long fro[TT];
     auto set_group = [&]() {
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
-            const int sq = fs + tt;
+            const int sq = fs + tt / LT, tok = (tt % LT) * 16 + lp;
             fro[tt] = -1;
-            if (tv && sq < send) fro[tt] = (long)(sq / inner) * P.outer_stride + (long)(sq % inner) * P.inner_stride + (long)lp * P.tok_stride + 8 * q;
+            if (tok < P.L && sq < send) fro[tt] = (long)(sq / inner) * P.outer_stride + (long)(sq % inner) * P.inner_stride + (long)tok * P.tok_stride + 8 * q;
         }
     };
     auto fetch = [&](uint4 (&dst)[TT]) {
@@ -1049,20 +1107,20 @@ __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, c
                 }
             }
         }
-        if (++fk == nkt) { fk = 0; fs += 8 * TT; set_group(); }
+        if (++fk == nkt) { fk = 0; fs += 8 * NS; set_group(); }
     };
     uint4 ring[4][TT];
     set_group();
 #pragma unroll
     for (int u = 0; u < 4; ++u) fetch(ring[u]);
 
-    for (int cs = s0 + w * TT; cs < send; cs += 8 * TT) {
-        long crow[TT];                                                // row index (x element offset / C) of token lp, or -1
+    for (int cs = s0 + w * NS; cs < send; cs += 8 * NS) {
+        long crow[TT];                                                // row index (x element offset / C) of this lane's token of tile tt, or -1
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
-            const int sq = cs + tt;
+            const int sq = cs + tt / LT, tok = (tt % LT) * 16 + lp;
             crow[tt] = -1;
-            if (tv && sq < send) crow[tt] = ((long)(sq / inner) * P.outer_stride + (long)(sq % inner) * P.inner_stride + (long)lp * P.tok_stride) / P.C;
+            if (tok < P.L && sq < send) crow[tt] = ((long)(sq / inner) * P.outer_stride + (long)(sq % inner) * P.inner_stride + (long)tok * P.tok_stride) / P.C;
         }
         f32x4 aq[TT][2], ak[TT][2], av[TT][2];
 #pragma unroll
@@ -1088,25 +1146,37 @@ __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, c
             }
         }
 #pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
-            f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f};                     // S^T[j, i] (unscaled): lane (i, q) holds keys j = 4q..4q+3
-            core_mma16<M, F8>(sc, ak[tt][0], aq[tt][0]);
-            core_mma16<M, F8>(sc, ak[tt][1], aq[tt][1]);
-            if (masked) {
+        for (int tt = 0; tt < TT; ++tt) {                             // query tile tt; its keys: the LT tiles of the same sequence
+            const int t0 = (tt / LT) * LT;
+            f32x4 sc[LT];                                             // S^T[j, i] (unscaled): lane (i, q) holds keys j = 16 tj + 4q..4q+3
+            float mx = -1e30f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (4 * q + r >= P.L) sc[r] = -1e30f;
+            for (int tj = 0; tj < LT; ++tj) {
+                sc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+                core_mma16<M, F8>(sc[tj], ak[t0 + tj][0], aq[tt][0]);
+                core_mma16<M, F8>(sc[tj], ak[t0 + tj][1], aq[tt][1]);
+                if (masked) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (tj * 16 + 4 * q + r >= P.L) sc[tj][r] = -1e30f;
+                }
+                mx = fmaxf(mx, fmaxf(fmaxf(sc[tj][0], sc[tj][1]), fmaxf(sc[tj][2], sc[tj][3])));
             }
-            const float mx = max_q(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])));
+            mx = max_q(mx);
             float sum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { sc[r] = __builtin_amdgcn_exp2f((sc[r] - mx) * escale); sum += sc[r]; }
+            for (int tj = 0; tj < LT; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { sc[tj][r] = __builtin_amdgcn_exp2f((sc[tj][r] - mx) * escale); sum += sc[tj][r]; }
             const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sc[r] *= inv;
+            for (int tj = 0; tj < LT; ++tj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sc[tj][r] *= inv;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
-                core_mma16<M, F8>(o, av[tt][t], sc);
+#pragma unroll
+                for (int tj = 0; tj < LT; ++tj) core_mma16<M, F8>(o, av[t0 + tj][t], sc[tj]);
                 if (crow[tt] >= 0) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.oscratch) + ((size_t)crow[tt] * HD + h * D + t * 16 + 4 * q) * 2) =
                                        make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
             }
@@ -1116,13 +1186,14 @@ __global__ __launch_bounds__(512) void attention_head_kernel(const AttnArgs P, c
 
 hipError_t launch_attention_heads(AttnArgs a, hipStream_t st) {
     a.CPad = conv_cin_pad(MODE_BF16, a.C);
-    if (a.heads != 8 || a.L > 16 || a.C % 128 || !a.oscratch || a.nseq >= (1L << 30)) return hipErrorInvalidValue;
+    if (a.heads != 8 || a.L > 64 || a.C % 128 || !a.oscratch || a.nseq >= (1L << 30)) return hipErrorInvalidValue;
     const size_t lds = (size_t)96 * (a.C * 2 + 32);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     constexpr int TT = 4;
-    // enough workgroups per head to fill the chip twice, at least one group of TT sequences per wave each
-    long spb = std::max<long>(8 * TT, (a.nseq * a.heads + 511) / 512);
-    spb = (spb + 8 * TT - 1) / (8 * TT) * (8 * TT);
+    const int LT = a.L <= 16 ? 1 : 4, NS = TT / LT;
+    // enough workgroups per head to fill the chip twice, at least one group of NS sequences per wave each
+    long spb = std::max<long>(8 * NS, (a.nseq * a.heads + 511) / 512);
+    spb = (spb + 8 * NS - 1) / (8 * NS) * (8 * NS);
     const long chunks = (a.nseq + spb - 1) / spb;
     auto go = [&](auto kfn) -> hipError_t {
         if (lds > 64 * 1024) {
@@ -1130,10 +1201,13 @@ hipError_t launch_attention_heads(AttnArgs a, hipStream_t st) {
             if (e != hipSuccess) return e;
         }
         const AttnWork aw = attn_work(a, 2, false);
-        LaunchScope ls(st, "attention_head_kernel", aw.flops, aw.bytes, "<io16 %d, %d, fp8 %d> C%d L%d nseq%ld", a.io_bf16, TT, a.fp8_core, a.C, a.L, a.nseq);
+        LaunchScope ls(st, "attention_head_kernel", aw.flops, aw.bytes, "<io16 %d, %d, fp8 %d, lt %d> C%d L%d nseq%ld", a.io_bf16, TT, a.fp8_core, LT, a.C, a.L, a.nseq);
         hipLaunchKernelGGL(kfn, dim3((unsigned)((chunks + 7) / 8 * 64)), dim3(512), lds, st, a, (int)spb, (int)chunks);
         return hipGetLastError();
     };
+    if (LT == 4) {                                     // (more than 16 tokens: the fp8 flag is ignored, as in the LDS-staged kernel)
+        return a.io_bf16 ? go(attention_head_kernel<true, TT, false, 4>) : go(attention_head_kernel<false, TT, false, 4>);
+    }
     if (a.fp8_core) return a.io_bf16 ? go(attention_head_kernel<true, TT, true>) : go(attention_head_kernel<false, TT, true>);
     return a.io_bf16 ? go(attention_head_kernel<true, TT, false>) : go(attention_head_kernel<false, TT, false>);
 }

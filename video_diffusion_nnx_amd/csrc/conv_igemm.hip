@@ -1226,6 +1226,308 @@ static hipError_t launch_conv64r(const ConvArgs& a, hipStream_t st) {
     return a.y_bf16 ? launch(conv64r_kernel<false, true>) : launch(conv64r_kernel<false, false>);
 }
 
+// ---- "conv64q": the weights-in-registers scheme with 16 output channels x 128 pixels per wave ------------------------------------------
+// conv64r_kernel's waves own 32 channels x 64 pixels: 144 weight registers, which leaves the prologue form no room (256 registers + scratch,
+// every coefficient re-read from LDS per piece: 449 us against conv64p_kernel's 422) and does not fit 128 input channels at all.  Here wave
+// (wc, wp) owns output channels 16 wc .. 16 wc + 15 of pixel rows 8 wp .. 8 wp + 7: 9 taps x CIN / 32 K chunks = 18 A fragments (72
+// registers) for CIN = 64, 36 (144) for CIN = 128.  Same three-deep LDS-DMA ring of 64-channel PLANES (a 128-channel tile = two plane
+// passes over persistent accumulators: the two tensors of a concat input, or the two halves of one), same column-keyed swizzle, same
+// sliding window: a fragment of halo row hr serves output rows hr, hr - 1, hr - 2; 60 fragment reads for 144 MFMAs per wave and pass.
+// Two finished rows are exchanged between the lane quads (v_permlane16_swap) so that a lane stores 8 consecutive channels = 16 bytes.
+// PRO (CIN = 64): GroupNorm-apply . (scale + 1) + shift -> SiLU applied IN PLACE to tile t + 1 while the MFMAs of tile t run; every thread
+// owns one 8-channel chunk of rows (tid >> 3) + 64 k, so its 16 coefficients stay in registers, and the piece of slot k + 1 is read from
+// LDS before the arithmetic of slot k.
+#ifndef VDX_C64Q_S0
+#define VDX_C64Q_S0 1
+#endif
+template <int CIN, bool PRO, bool OUT16>
+__global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
+    using M = Mma<MODE_BF16>;
+    static_assert(CIN == 64 || (CIN == 128 && !PRO), "prologue form: 64 input channels");
+    constexpr int NPL = CIN / 64;                     // 64-channel planes per tile
+    constexpr int NDMA = 41, NK = (NDMA + 7) / 8;
+    constexpr int NST = OUT16 ? 4 : 8;                // row stores of a wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Al = smem;                                  // [3][328 rows][128 B]
+    double* chs = reinterpret_cast<double*>(Al + 3 * C64D_APL);   // [2][64] channel sum / sumsq of the current sample (f64: order-independent)
+    float* biasl = reinterpret_cast<float*>(chs + 128);           // [64]
+    float* coefA = biasl + 64;                                    // PRO: [64] x -> silu(x * coefA + coefD)
+    float* coefD = coefA + 64;
+    float* gmean = coefD + 64;                                    // [32][mean, rstd]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc = wave_u & 3, wp = wave_u >> 2;      // output-channel quarter, pixel half (rows 8 wp .. 8 wp + 7)
+    const int lp = lane & 15, q = lane >> 4;
+    const int tiles_x = P.W >> 4, tiles_pf = tiles_x * (P.H >> 4);
+    const int t0 = blockIdx.x * tiles_per_block, t1 = min(t0 + tiles_per_block, total_tiles);
+    if (t0 >= t1) return;
+
+    // this wave's weights: packed [tap][wrows][CIN ci] bf16; fragment (tap, K chunk c) of lane (lp, q) = ci 32 c + 8 q .. + 7 of row 16 wc + lp
+    uint4 wf[9][CIN / 32];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int c = 0; c < CIN / 32; ++c)
+            wf[tap][c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) +
+                ((size_t)tap * P.wrows + P.wrow0 + wc * 16 + lp) * (CIN * 2) + c * 64 + q * 16);
+    if (tid < 128) chs[tid] = 0.0;
+    if (tid < 64) biasl[tid] = P.bias ? P.bias[tid] : 0.f;
+
+    const char* const zero_page = reinterpret_cast<const char*>(g_zero_page_c64d);
+    const char* const xb0 = reinterpret_cast<const char*>(P.x0);
+    const char* const xb1 = (CIN == 128) ? (P.C1 ? reinterpret_cast<const char*>(P.x1) : xb0 + 128) : xb0;   // plane 1: second tensor, or channels 64..127
+    const int rowb = (CIN == 128 && !P.C1) ? 256 : 128;          // bytes per pixel of a plane's tensor
+    const unsigned al_base = lds_addr(Al);
+    auto decode = [&](int t, int& f, int& ty, int& tx) { f = t / tiles_pf; const int r = t - f * tiles_pf; ty = r / tiles_x; tx = r - ty * tiles_x; };
+    // plane pass j = t * NPL + plane lives in ring buffer j % 3
+    auto dma = [&](int t, int plane, int buf) {
+        int f, ty, tx; decode(t, f, ty, tx);
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const char* const xb = plane ? xb1 : xb0;
+        const unsigned dst = al_base + buf * C64D_APL + wave_u * 1024;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            if (wave_u + 8 * k >= NDMA) continue;     // (uniform)
+            const int hp = (wave_u + 8 * k) * 8 + (ln >> 3);
+            const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;          // hp / 18, hp % 18 for hp < 328
+            const int gy = ty * 16 - 1 + hy, gx = tx * 16 - 1 + hx;
+            const bool ok = hp < C64_HALO && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+            const size_t off = (size_t)((f * P.H + gy) * P.W + gx) * rowb + (((ln & 7) ^ (hx & 7)) << 4);
+            glds16(ok ? static_cast<const void*>(xb + off) : static_cast<const void*>(zero_page), dst + k * 8 * 1024);
+        }
+    };
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, (unsigned)P.NF * P.H * P.W * 64u * (OUT16 ? 2u : 4u), 0x00020000);
+    // statistics of this lane's 8 channels 16 wc + 8 (q >> 1) + i (rows of both parities)
+    float ssum[8], ssq[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ssum[i] = 0.f; ssq[i] = 0.f; }
+    auto flush_stats = [&](int b) {
+        if (!P.out_stats) return;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float s1 = reduce16(ssum[i]), s2 = reduce16(ssq[i]);
+            const int c = wc * 16 + 8 * (q >> 1) + i;
+            if (lp == 0) { unsafeAtomicAdd(&chs[c], (double)s1); unsafeAtomicAdd(&chs[64 + c], (double)s2); }
+            ssum[i] = 0.f; ssq[i] = 0.f;
+        }
+        __syncthreads();
+        const int cpg = 64 / P.out_groups;
+        int tt = tid;
+        asm volatile("" : "+v"(tt));
+        if (tt < 2 * P.out_groups) {
+            const int g = tt >> 1, which = tt & 1;
+            double t = 0.0;
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) t += chs[which * 64 + c];
+            unsafeAtomicAdd(P.out_stats + (((size_t)b * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * P.out_groups + g) * 2 + which, t);
+        }
+        __syncthreads();
+        if (tid < 128) chs[tid] = 0.0;
+        __syncthreads();
+    };
+    // PRO: this thread's channel chunk and coefficients
+    const int tch = tid & 7, trow = tid >> 3;         // chunk 8 tch .. 8 tch + 7 of halo rows trow + 64 k
+    float ca[PRO ? 8 : 1], cd[PRO ? 8 : 1];
+    auto make_coef = [&](int b) {                     // (all threads call; contains barriers)
+        if constexpr (PRO) {
+            gn_mean_rstd_wg(P.in_stats, b, P.groups, (double)P.F * P.H * P.W * (64 / P.groups), gmean, tid, 512);
+            __syncthreads();
+            int tt = tid;
+            asm volatile("" : "+v"(tt));
+            if (tt < 64) {
+                const int g = tt / (64 / P.groups);
+                const float m = gmean[2 * g], rsd = gmean[2 * g + 1];
+                float sc = 1.f, sh = 0.f;
+                if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + tt] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + 64 + tt]; }
+                coefA[tt] = rsd * P.gamma[tt] * sc;
+                coefD[tt] = (P.beta[tt] - m * rsd * P.gamma[tt]) * sc + sh;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { ca[i] = coefA[8 * tch + i]; cd[i] = coefD[8 * tch + i]; }
+        }
+    };
+    // LDS byte offset (inside a plane buffer) of this thread's piece of round k, and whether the piece is inside the image
+    auto piece_off = [&](int k) __attribute__((always_inline)) -> int {
+        const int hp = trow + 64 * k;
+        const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;
+        return hp * 128 + ((tch ^ (hx & 7)) << 4);
+    };
+    auto piece_ok = [&](int k, int ty, int tx) __attribute__((always_inline)) -> bool {
+        const int hp = trow + 64 * k;
+        const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;
+        const int gy = ty * 16 - 1 + hy, gx = tx * 16 - 1 + hx;
+        return hp < C64_HALO && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
+    };
+    auto piece_math = [&](u32x4 v, bool ok) __attribute__((always_inline)) -> u32x4 {
+        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+        unsigned o4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = silu_f(fmaf(__uint_as_float(w4[j] << 16), ca[PRO ? 2 * j : 0], cd[PRO ? 2 * j : 0]));
+            const float hi = silu_f(fmaf(__uint_as_float(w4[j] & 0xFFFF0000u), ca[PRO ? 2 * j + 1 : 0], cd[PRO ? 2 * j + 1 : 0]));
+            o4[j] = ok ? pack_bf16x2(lo, hi) : 0u;    // zero padding stays zero AFTER the activation
+        }
+        return u32x4{o4[0], o4[1], o4[2], o4[3]};
+    };
+    constexpr int NPK = 6;                            // rounds of 64 rows: 324 = 5 x 64 + 4 (the last round is wave 0's lanes 0..31 only)
+    auto piece_live = [&](int k) __attribute__((always_inline)) -> bool { return k < NPK - 1 || wave_u == 0; };   // (uniform)
+
+    // fragment addressing: B fragment of (halo row hr of this wave, dx, K chunk ch) = At + rowbase + bdx[dx][ch] + hr * 18 * 128
+    int bdx[3][2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) { const int hx = lp + dx; bdx[dx][ch] = hx * 128 + 16 * ((q + 4 * ch) ^ (hx & 7)); }
+    const int rowbase = (8 * wp) * 18 * 128;          // (wave-uniform)
+
+    int fcur, tyc, txc;
+    decode(t0, fcur, tyc, txc);
+    int bcur = fcur / P.F;
+    __syncthreads();                                  // chs + bias visible
+    // passes in flight: j = 0 (and 1) issued here, j + 2 at the top of pass j
+    const int npass = (t1 - t0) * NPL;
+    dma(t0, 0, 0);
+    if (npass > 1) dma(NPL == 1 ? t0 + 1 : t0, NPL == 1 ? 0 : 1, 1);
+    // pass 0 has landed (a wave issues 5 or 6 instructions per pass); PRO: pass 1 too -- it is transformed during pass 0, so a pass's DMA
+    // has ONE period to land (buffers: computing / being transformed / landing), the plain form's has two
+    if (npass > 1 && !PRO) wait_vm<5>(); else wait_vm<0>();
+    int bcoef = bcur;
+    if constexpr (PRO) {
+        make_coef(bcur);                              // (its barriers also make pass 0 visible to every thread)
+#pragma unroll
+        for (int k = 0; k < NPK; ++k) {
+            if (!piece_live(k)) continue;
+            char* pp = Al + piece_off(k);
+            if (trow + 64 * k < C64D_AROWS) *reinterpret_cast<u32x4*>(pp) = piece_math(*reinterpret_cast<const u32x4*>(pp), piece_ok(k, tyc, txc));
+        }
+    }
+    __syncthreads();
+    int buf = 0, j = 0;                               // ring buffer and index of the current pass
+    f32x4 acc[8];
+    for (int t = t0; t < t1; ++t) {
+        const bool more = t + 1 < t1;
+        int fn = fcur, tyn = tyc, txn = txc, bn = bcur;
+        if (more) { decode(t + 1, fn, tyn, txn); bn = fn / P.F; }
+        const int oy0 = tyc * 16 + 8 * wp, ox = txc * 16 + lp;
+#pragma unroll
+        for (int plane = 0; plane < NPL; ++plane, ++j) {
+            if (j + 2 < npass) {                      // (buf + 2) % 3: the buffer of pass j - 1, last read before the previous barrier
+                const int j2 = j + 2;
+                dma(t0 + j2 / NPL, NPL == 1 ? 0 : (j2 & 1), buf >= 1 ? buf - 1 : 2);
+            }
+            const int bufn = buf == 2 ? 0 : buf + 1;
+            const char* At = Al + buf * C64D_APL + rowbase;
+            char* const An = Al + bufn * C64D_APL;    // PRO: the tile being transformed
+            uint4 bf[2][3];                           // fragments of step s = 2 hr + ch in bf[s & 1]: step s + 1 is read before step s's MFMAs
+            auto frag_read = [&](uint4 (&d)[3], int hr, int ch) __attribute__((always_inline)) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) d[dx] = *reinterpret_cast<const uint4*>(At + bdx[dx][ch] + hr * (18 * 128));
+            };
+            u32x4 pv;                                 // PRO: the piece of the next slot, read one slot ahead
+            bool pok = false;
+            if constexpr (PRO) { if (more) { pv = *reinterpret_cast<const u32x4*>(An + piece_off(0)); pok = piece_ok(0, tyn, txn); } }
+            frag_read(bf[0], 0, 0);
+#pragma unroll
+            for (int hr = 0; hr < 10; ++hr) {
+                if (plane == 0 && hr < 8) acc[hr] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const int s_ = 2 * hr + ch;
+                    if (s_ + 1 < 20) frag_read(bf[(s_ + 1) & 1], (s_ + 1) >> 1, (s_ + 1) & 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int tn = hr - dy;
+                            if (tn < 0 || tn > 7) continue;
+                            M::mma(acc[tn], wf[dy * 3 + dx][plane * 2 + ch], bf[s_ & 1][dx]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (PRO) {              // slot k of the next tile's prologue behind step 3 k + VDX_C64Q_S0
+                        const int so = s_ - VDX_C64Q_S0;
+                        if (more && so >= 0 && so % 3 == 0 && so / 3 < NPK) {
+                            const int k = so / 3;
+                            if (piece_live(k)) {
+                                const u32x4 cur = pv;
+                                const bool okc = pok;
+                                if (k + 1 < NPK && piece_live(k + 1) && trow + 64 * (k + 1) < C64D_AROWS) { pv = *reinterpret_cast<const u32x4*>(An + piece_off(k + 1)); pok = piece_ok(k + 1, tyn, txn); }
+                                if (trow + 64 * k < C64D_AROWS) *reinterpret_cast<u32x4*>(An + piece_off(k)) = piece_math(cur, okc);
+                            }
+                        }
+                    }
+                }
+                // rows hr - 3 (even) and hr - 2 are finished once halo row hr has been consumed in the LAST plane: exchange the lane quads so
+                // that lane (px, q) holds row (hr - 3) + (q & 1), channels 16 wc + 8 (q >> 1) .. + 7, add the bias, take the statistics, store
+                if (plane == NPL - 1 && hr >= 3 && (hr & 1)) {
+                    const int ta = hr - 3;
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ta][r]), __float_as_uint(acc[ta + 1][r]), false, false);
+                        v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
+                    }
+                    const float4 b0 = *reinterpret_cast<const float4*>(biasl + wc * 16 + 8 * (q >> 1)), b1 = *reinterpret_cast<const float4*>(biasl + wc * 16 + 8 * (q >> 1) + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { ssum[i] += v[i]; ssq[i] += v[i] * v[i]; }
+                    const unsigned gout = (unsigned)(((fcur * P.H + oy0 + ta + (q & 1)) * P.W + ox) * 64 + wc * 16 + 8 * (q >> 1));
+                    if constexpr (OUT16)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rsy, gout * 2u, 0, 0);
+                    else {
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsy, gout * 4u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rsy, (gout + 4) * 4u, 0, 0);
+                    }
+                }
+            }
+            // pass j + 1 has landed: everything older than this pass's DMA (5 or 6 instructions, when issued) and the row stores of the last plane
+            if constexpr (PRO) wait_vm<NST>();        // (the DMA issued at the top of this pass: the next pass transforms it)
+            else {
+                const bool issued = j + 2 < npass;
+                if (plane == NPL - 1) { if (issued) wait_vm<5 + NST>(); else wait_vm<NST>(); }
+                else { if (issued) wait_vm<5>(); else wait_vm<0>(); }
+            }
+            if (plane == NPL - 1) {
+                if (more && bn != bcur) { flush_stats(bcur); bcur = bn; }    // uniform: the next tile belongs to another sample
+                if constexpr (PRO) {
+                    // coefficients of the sample tile t + 2 belongs to, before its transform starts (make_coef begins with a barrier behind
+                    // every transform of this iteration)
+                    if (t + 2 < t1) { int f2, ty2, tx2; decode(t + 2, f2, ty2, tx2); const int b2 = f2 / P.F; if (b2 != bcoef) { make_coef(b2); bcoef = b2; } }
+                }
+            }
+            buf = bufn;
+            __syncthreads();                          // pass j + 1 landed everywhere (PRO: tile t + 1 transformed); everybody is done reading pass j
+        }
+        fcur = fn; tyc = tyn; txc = txn;
+    }
+    flush_stats(bcur);
+}
+
+static hipError_t launch_conv64q(const ConvArgs& a, hipStream_t st) {
+    const int total = a.NF * (a.H >> 4) * (a.W >> 4);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const int grid = std::min(total, cus);
+    const int tpb = (total + grid - 1) / grid;
+    const int nblocks = (total + tpb - 1) / tpb;
+    const size_t lds = 3 * (size_t)C64D_APL + 128 * 8 + 64 * 4 + (64 + 64 + 64) * 4;
+    auto launch = [&](auto kfn) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(512), lds, st, a, tpb, total);
+        return hipGetLastError();
+    };
+    if (!a.x0_bf16 || a.res || (a.C1 && !a.x1_bf16)) return hipErrorInvalidValue;
+    if (a.C0 + a.C1 == 128) {
+        if (a.pro) return hipErrorInvalidValue;
+        return a.y_bf16 ? launch(conv64q_kernel<128, false, true>) : launch(conv64q_kernel<128, false, false>);
+    }
+    if (a.pro) return a.y_bf16 ? launch(conv64q_kernel<64, true, true>) : launch(conv64q_kernel<64, true, false>);
+    return a.y_bf16 ? launch(conv64q_kernel<64, false, true>) : launch(conv64q_kernel<64, false, false>);
+}
+
 static hipError_t launch_conv64p(const ConvArgs& a, hipStream_t st) {
     const int total = a.NF * (a.H >> 4) * (a.W >> 4);
     int dev = 0, cus = 256;
@@ -1660,8 +1962,16 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
 #define VDX_C64R 1
 #endif
 #ifndef VDX_C64R_PRO
-#define VDX_C64R_PRO 1
+#define VDX_C64R_PRO 0       // the prologue form of conv64r_kernel measured SLOWER than conv64p_kernel (449 vs 422 us at level 0, r03): built, tested, not dispatched
 #endif
+#ifndef VDX_C64Q
+#define VDX_C64Q 7             // conv64q_kernel (16 channels x 128 pixels per wave) for: 1 = the prologue form, 2 = the plain form, 4 = 128 input channels
+#endif
+            if (a.x0_bf16 && !a.res && !VDX_C64_NODMA && (VDX_C64Q & (a.pro ? 1 : 2))) {
+                const ConvWork cw = conv_work(mode, a);
+                LaunchScope ls(st, "conv64q_kernel", cw.flops, cw.bytes, "<cin 64, pro %d, y16 %d> %s", a.pro, a.y_bf16, cw.shape);
+                return launch_conv64q(a, st);
+            }
             if (VDX_C64R && a.x0_bf16 && !a.res && !VDX_C64_NODMA && (!a.pro || VDX_C64R_PRO)) {      // weights in registers, three-deep tile ring (conv64r_kernel)
                 const ConvWork cw = conv_work(mode, a);
                 LaunchScope ls(st, "conv64r_kernel", cw.flops, cw.bytes, "<pro %d, y16 %d> %s", a.pro, a.y_bf16, cw.shape);
@@ -1684,6 +1994,10 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
             ((a.C0 == 64 && a.C1 == 64) || (a.C0 == 128 && a.C1 == 0)) && a.wrows == 64 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 &&
             tiles >= 1024 && (!a.out_stats || (a.out_groups <= 32 && 32 % (64 / a.out_groups) == 0 && 64 % a.out_groups == 0))) {
             const ConvWork cw = conv_work(mode, a);
+            if ((VDX_C64Q & 4) && (long)a.NF * a.H * a.W * 256 < 0xFFFFFFF0l) {
+                LaunchScope ls(st, "conv64q_kernel", cw.flops, cw.bytes, "<cin 128, pro 0, y16 %d> %s", a.y_bf16, cw.shape);
+                return launch_conv64q(a, st);
+            }
             LaunchScope ls(st, "conv128x64p_kernel", cw.flops, cw.bytes, "%s", cw.shape);
             return launch_conv128x64p(a, st);
         }

@@ -435,7 +435,7 @@ static hipError_t run_attn(const Fwd& f, const AttnP& ap, const float* x, float*
     }
     // wide levels in bf16 mode: per-head kernel (weights resident in LDS) + the out-projection as a 1x1 conv
     const int use_heads = 1;
-    if (use_heads && m->mode == MODE_BF16 && temporal && a.L <= 16 && a.heads == 8 && ap.C >= 256 && ap.C % 128 == 0 &&
+    if (use_heads && m->mode == MODE_BF16 && (temporal ? a.L <= 16 : a.L <= 64) && a.heads == 8 && ap.C >= 256 && ap.C % 128 == 0 &&
         (size_t)96 * (ap.C * 2 + 32) <= 160 * 1024 && (size_t)Fr * S * S * a.heads * 64 <= m->sla_ws_bytes_per_sample) {
         a.oscratch = f.sla_ws;
         hipError_t e = launch_attention_heads(a, f.st);
