@@ -16,6 +16,7 @@
 // (the 9 taps re-read it with shifted per-lane addresses); the weight tile of each tap streams through
 // a 2-deep register->LDS ring.  Accumulators: lane (r,q) holds channels 4q..4q+3 of pixel r (vdx_common.h).
 #include "vdx_common.h"
+#include <type_traits>
 #include "vdx_internal.h"
 #include "vdx_glds.h"
 #include "model.h"
@@ -1237,8 +1238,8 @@ static hipError_t launch_conv64r(const ConvArgs& a, hipStream_t st) {
 // PRO (CIN = 64): GroupNorm-apply . (scale + 1) + shift -> SiLU applied IN PLACE to tile t + 1 while the MFMAs of tile t run; every thread
 // owns one 8-channel chunk of rows (tid >> 3) + 64 k, so its 16 coefficients stay in registers, and the piece of slot k + 1 is read from
 // LDS before the arithmetic of slot k.
-#ifndef VDX_C64Q_S0
-#define VDX_C64Q_S0 1
+#ifndef VDX_C64Q_VPM
+#define VDX_C64Q_VPM 6        // VALU instructions of the prologue behind each MFMA of a transform step
 #endif
 template <int CIN, bool PRO, bool OUT16>
 __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
@@ -1420,68 +1421,97 @@ __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const in
             const int bufn = buf == 2 ? 0 : buf + 1;
             const char* At = Al + buf * C64D_APL + rowbase;
             char* const An = Al + bufn * C64D_APL;    // PRO: the tile being transformed
-            uint4 bf[2][3];                           // fragments of step s = 2 hr + ch in bf[s & 1]: step s + 1 is read before step s's MFMAs
-            auto frag_read = [&](uint4 (&d)[3], int hr, int ch) __attribute__((always_inline)) {
+            // The hr / K-chunk steps of the pass.  XF (PRO, a next tile exists): the prologue of tile t + 1 rides in the MFMA shadows of
+            // steps 4..13 (9 MFMAs each): half a piece (4 channels: 32 VALU) per step, laid out MFMA, 4 VALU, MFMA, 4 VALU, ... by
+            // sched_group_barrier -- behind the step's MFMAs as a block (first form) the matrix pipe idled while both waves of a SIMD ran
+            // their SiLU at the same time, and the prologue form cost its whole VALU time on top of the plain form (410-446 vs 300 us).
+            auto steps = [&](auto xf_tag) __attribute__((always_inline)) {
+                constexpr bool XF = decltype(xf_tag)::value;
+                uint4 bf[2][3];                       // fragments of step s = 2 hr + ch in bf[s & 1]: step s + 1 is read before step s's MFMAs
+                auto frag_read = [&](uint4 (&d)[3], int hr, int ch) __attribute__((always_inline)) {
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) d[dx] = *reinterpret_cast<const uint4*>(At + bdx[dx][ch] + hr * (18 * 128));
-            };
-            u32x4 pv;                                 // PRO: the piece of the next slot, read one slot ahead
-            bool pok = false;
-            if constexpr (PRO) { if (more) { pv = *reinterpret_cast<const u32x4*>(An + piece_off(0)); pok = piece_ok(0, tyn, txn); } }
-            frag_read(bf[0], 0, 0);
+                    for (int dx = 0; dx < 3; ++dx) d[dx] = *reinterpret_cast<const uint4*>(At + bdx[dx][ch] + hr * (18 * 128));
+                };
+                auto half_math = [&](unsigned w0, unsigned w1, int cb, bool ok, unsigned& o0, unsigned& o1) __attribute__((always_inline)) {
+                    const float a0 = silu_f(fmaf(__uint_as_float(w0 << 16), ca[PRO ? cb : 0], cd[PRO ? cb : 0]));
+                    const float a1 = silu_f(fmaf(__uint_as_float(w0 & 0xFFFF0000u), ca[PRO ? cb + 1 : 0], cd[PRO ? cb + 1 : 0]));
+                    const float a2 = silu_f(fmaf(__uint_as_float(w1 << 16), ca[PRO ? cb + 2 : 0], cd[PRO ? cb + 2 : 0]));
+                    const float a3 = silu_f(fmaf(__uint_as_float(w1 & 0xFFFF0000u), ca[PRO ? cb + 3 : 0], cd[PRO ? cb + 3 : 0]));
+                    const unsigned keep = ok ? 0xFFFFFFFFu : 0u;       // zero padding stays zero AFTER the activation (a mask, not a select around
+                    o0 = pack_bf16x2(a0, a1) & keep;                   // the arithmetic: the compiler turns that into a branch over it, which
+                    o1 = pack_bf16x2(a2, a3) & keep;                   // cuts the MFMA / VALU interleave region in two)
+                };
+                u32x4 pv = u32x4{0u, 0u, 0u, 0u}, cur = pv;   // XF: the piece of the next slot (read one slot ahead) / of this slot
+                bool pok = false, okc = false;
+                unsigned oh0 = 0u, oh1 = 0u;
+                if constexpr (XF) { pv = *reinterpret_cast<const u32x4*>(An + piece_off(0)); pok = piece_ok(0, tyn, txn); }
+                frag_read(bf[0], 0, 0);
 #pragma unroll
-            for (int hr = 0; hr < 10; ++hr) {
-                if (plane == 0 && hr < 8) acc[hr] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int hr = 0; hr < 10; ++hr) {
+                    if (plane == 0 && hr < 8) acc[hr] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ch = 0; ch < 2; ++ch) {
-                    const int s_ = 2 * hr + ch;
-                    if (s_ + 1 < 20) frag_read(bf[(s_ + 1) & 1], (s_ + 1) >> 1, (s_ + 1) & 1);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const int s_ = 2 * hr + ch;
+                        if (s_ + 1 < 20) frag_read(bf[(s_ + 1) & 1], (s_ + 1) >> 1, (s_ + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx)
+                        for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) {
-                            const int tn = hr - dy;
-                            if (tn < 0 || tn > 7) continue;
-                            M::mma(acc[tn], wf[dy * 3 + dx][plane * 2 + ch], bf[s_ & 1][dx]);
+                            for (int dy = 0; dy < 3; ++dy) {
+                                const int tn = hr - dy;
+                                if (tn < 0 || tn > 7) continue;
+                                M::mma(acc[tn], wf[dy * 3 + dx][plane * 2 + ch], bf[s_ & 1][dx]);
+                            }
+                        if constexpr (XF) {
+                            const int c = s_ - 4;     // half-piece slot: rounds k = 0..4 of 64 rows
+                            if (c >= 0 && c < 10) {
+                                const int k = c >> 1;
+                                if ((c & 1) == 0) {
+                                    cur = pv; okc = pok;
+                                    if (k + 1 < NPK - 1) { pv = *reinterpret_cast<const u32x4*>(An + piece_off(k + 1)); pok = piece_ok(k + 1, tyn, txn); }
+                                    half_math(cur.x, cur.y, 0, okc, oh0, oh1);
+                                } else {
+                                    unsigned o2, o3;
+                                    half_math(cur.z, cur.w, 4, okc, o2, o3);
+                                    *reinterpret_cast<u32x4*>(An + piece_off(k)) = u32x4{oh0, oh1, o2, o3};
+                                }
+#pragma unroll
+                                for (int i = 0; i < 9; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, VDX_C64Q_VPM, 0); }
+                            }
                         }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (PRO) {              // slot k of the next tile's prologue behind step 3 k + VDX_C64Q_S0
-                        const int so = s_ - VDX_C64Q_S0;
-                        if (more && so >= 0 && so % 3 == 0 && so / 3 < NPK) {
-                            const int k = so / 3;
-                            if (piece_live(k)) {
-                                const u32x4 cur = pv;
-                                const bool okc = pok;
-                                if (k + 1 < NPK && piece_live(k + 1) && trow + 64 * (k + 1) < C64D_AROWS) { pv = *reinterpret_cast<const u32x4*>(An + piece_off(k + 1)); pok = piece_ok(k + 1, tyn, txn); }
-                                if (trow + 64 * k < C64D_AROWS) *reinterpret_cast<u32x4*>(An + piece_off(k)) = piece_math(cur, okc);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (XF) {
+                            if (s_ == 14 && wave_u == 0 && trow + 64 * (NPK - 1) < C64D_AROWS) {     // the last 4 (+ 4 padding) rows: wave 0's lanes 0..31
+                                char* pp = An + piece_off(NPK - 1);
+                                *reinterpret_cast<u32x4*>(pp) = piece_math(*reinterpret_cast<const u32x4*>(pp), piece_ok(NPK - 1, tyn, txn));
                             }
                         }
                     }
-                }
-                // rows hr - 3 (even) and hr - 2 are finished once halo row hr has been consumed in the LAST plane: exchange the lane quads so
-                // that lane (px, q) holds row (hr - 3) + (q & 1), channels 16 wc + 8 (q >> 1) .. + 7, add the bias, take the statistics, store
-                if (plane == NPL - 1 && hr >= 3 && (hr & 1)) {
-                    const int ta = hr - 3;
-                    float v[8];
+                    // rows hr - 3 (even) and hr - 2 are finished once halo row hr has been consumed in the LAST plane: exchange the lane quads so
+                    // that lane (px, q) holds row (hr - 3) + (q & 1), channels 16 wc + 8 (q >> 1) .. + 7, add the bias, take the statistics, store
+                    if (plane == NPL - 1 && hr >= 3 && (hr & 1)) {
+                        const int ta = hr - 3;
+                        float v[8];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ta][r]), __float_as_uint(acc[ta + 1][r]), false, false);
-                        v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
-                    }
-                    const float4 b0 = *reinterpret_cast<const float4*>(biasl + wc * 16 + 8 * (q >> 1)), b1 = *reinterpret_cast<const float4*>(biasl + wc * 16 + 8 * (q >> 1) + 4);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                        for (int r = 0; r < 4; ++r) {
+                            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ta][r]), __float_as_uint(acc[ta + 1][r]), false, false);
+                            v[r] = __uint_as_float(sw[0]); v[4 + r] = __uint_as_float(sw[1]);
+                        }
+                        const float4 b0 = *reinterpret_cast<const float4*>(biasl + wc * 16 + 8 * (q >> 1)), b1 = *reinterpret_cast<const float4*>(biasl + wc * 16 + 8 * (q >> 1) + 4);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { ssum[i] += v[i]; ssq[i] += v[i] * v[i]; }
-                    const unsigned gout = (unsigned)(((fcur * P.H + oy0 + ta + (q & 1)) * P.W + ox) * 64 + wc * 16 + 8 * (q >> 1));
-                    if constexpr (OUT16)
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rsy, gout * 2u, 0, 0);
-                    else {
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsy, gout * 4u, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rsy, (gout + 4) * 4u, 0, 0);
+                        for (int i = 0; i < 8; ++i) { ssum[i] += v[i]; ssq[i] += v[i] * v[i]; }
+                        const unsigned gout = (unsigned)(((fcur * P.H + oy0 + ta + (q & 1)) * P.W + ox) * 64 + wc * 16 + 8 * (q >> 1));
+                        if constexpr (OUT16)
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rsy, gout * 2u, 0, 0);
+                        else {
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rsy, gout * 4u, 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rsy, (gout + 4) * 4u, 0, 0);
+                        }
                     }
                 }
-            }
+            };
+            if (PRO && more) steps(std::true_type{}); else steps(std::false_type{});
             // pass j + 1 has landed: everything older than this pass's DMA (5 or 6 instructions, when issued) and the row stores of the last plane
             if constexpr (PRO) wait_vm<NST>();        // (the DMA issued at the top of this pass: the next pass transforms it)
             else {
@@ -1965,7 +1995,7 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
 #define VDX_C64R_PRO 0       // the prologue form of conv64r_kernel measured SLOWER than conv64p_kernel (449 vs 422 us at level 0, r03): built, tested, not dispatched
 #endif
 #ifndef VDX_C64Q
-#define VDX_C64Q 7             // conv64q_kernel (16 channels x 128 pixels per wave) for: 1 = the prologue form, 2 = the plain form, 4 = 128 input channels
+#define VDX_C64Q 5             // conv64q_kernel (16 channels x 128 pixels per wave) for: 1 = the prologue form, 2 = the plain form, 4 = 128 input channels
 #endif
             if (a.x0_bf16 && !a.res && !VDX_C64_NODMA && (VDX_C64Q & (a.pro ? 1 : 2))) {
                 const ConvWork cw = conv_work(mode, a);
