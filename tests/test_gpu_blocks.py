@@ -185,7 +185,10 @@ ATTN16_CASES = [
     (1, 16, 96, 93, 64),       # 2232 groups: 2 per wave, last workgroup has 8 groups for 8 waves x 2
     (3, 16, 64, 48, 64),       # 2304 groups, 3 samples
     (1, 16, 8, 8, 64),         # 64 sequences: below the threshold -> attention_h8_kernel FULL form
-    (1, 12, 16, 16, 64),       # 12 frames: masked attention_h8_kernel
+    (1, 12, 16, 16, 64),       # 12 frames: the masked form of attention_w_kernel (keys >= L masked, rows of tokens >= L not touched)
+    (1, 16, 16, 16, 32),       # C = 32 (level 0 of dim-32 networks): one K chunk, one pair of output tiles
+    (2, 10, 24, 22, 32),       # the YAML-literal config_v2_2's temporal attention: C = 32, 10 frames, 264 groups over two samples
+    (1, 10, 8, 8, 32),         # below the threshold: attention_h8_kernel C = 32 form
     (1, 16, 8, 8, 128),
 ]
 
@@ -209,6 +212,11 @@ def test_attention_bf16_tensors(case):
     assert rel_branch < 4e-2 and rel < 1e-2, (case, rel_branch, rel)
     y2 = ops.attention_forward_bf16(x.to(DEV), packed, 8, True)
     assert torch.equal(y, y2)                      # no order-dependent sums: bit-reproducible
+    if case in (ATTN16_CASES[0], ATTN16_CASES[7]):  # the fp8 (e4m3) QK^T / PV core of the same kernels (parity unpinned; stated 1e-1 as above)
+        y8 = ops.attention_forward_bf16(x.to(DEV), packed, 8, True, fp8_core=True).cpu().double()
+        r8 = _rel(y8 - xd, o)
+        print(f'   fp8 core: branch {r8:.3e}')
+        assert rel_branch * 1.5 < r8 < 1e-1, (case, r8, rel_branch)
 
 
 # fp8 attention core (vdx_set_attention_fp8 / BASELINE.json configs[4]): q, k, v and the softmax probabilities of the <= 16-token

@@ -800,15 +800,20 @@ static hipError_t launch_attn_h8_t(const AttnArgs& a, hipStream_t st) {
 #ifndef VDX_AW_NW
 #define VDX_AW_NW 8           // waves per workgroup (8 = 2 per SIMD at <= 256 registers, 12 = 3 at <= 168)
 #endif
-template <bool F8>
+// C = 64 or 32 (level 0 of dim-32 networks, the YAML-literal config_v2_2: one K chunk -- the packed rows are padded to 64 channels with
+// zeros --, 32 output channels = one pair of tiles); FULL: sequences of exactly 16 tokens, else keys >= L are masked and the rows of
+// tokens >= L neither loaded nor stored
+template <bool F8, int C = 64, bool FULL = true>
 __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnArgs P, const int groups_per_wave, const long ngroups) {
     using M = Mma<MODE_BF16>;
     constexpr int HD = 256, D = 32, SB = VDX_AW_SB, NT = 64 * VDX_AW_NW;
+    constexpr int NCH = C / 32, NTL = C / 16;           // K chunks of the projections, output-channel tiles
+    static_assert(C == 64 || C == 32, "C");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Wq = smem;                                   // [768 rows][128 B]: 16-byte chunk c of row r at r * 128 + 16 * (c ^ (r & 7))
     char* Wo = Wq + 3 * HD * 128;                      // [64 rows][512 B]: row R = 16 * tile + i holds channel 32 (tile >> 1) + 8 (i >> 2) + 4 (tile & 1) + (i & 3);
                                                        // piece (head h, q) = d {4q..4q+3, 16+4q..16+4q+3} at 16 * ((4 h + q) ^ (R & 15))
-    float* bl = reinterpret_cast<float*>(Wo + 64 * 512);   // bqkv [768] | bo [64]
+    float* bl = reinterpret_cast<float*>(Wo + C * 512);    // bqkv [768] | bo [C]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lp = lane & 15, q = lane >> 4;
@@ -817,7 +822,7 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
         const int r = i >> 3, c = i & 7;
         *reinterpret_cast<uint4*>(Wq + r * 128 + 16 * (c ^ (r & 7))) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wqkv) + (size_t)r * 128 + c * 16);
     }
-    for (int i = tid; i < 64 * 32; i += NT) {
+    for (int i = tid; i < C * 32; i += NT) {
         const int R = i >> 5, c = i & 31, hh = c >> 2, qq = c & 3;
         const int tile = R >> 4, ri = R & 15;
         const int co = 32 * (tile >> 1) + 8 * (ri >> 2) + 4 * (tile & 1) + (ri & 3);
@@ -826,7 +831,7 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
         *reinterpret_cast<uint4*>(Wo + R * 512 + 16 * (c ^ (R & 15))) = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
     for (int i = tid; i < 3 * HD; i += NT) bl[i] = P.bqkv[i];
-    if (tid < 64) bl[3 * HD + tid] = P.bo[tid];
+    if (tid < C) bl[3 * HD + tid] = P.bo[tid];
     __syncthreads();                                   // the only barrier: weights visible
 
     const long g_first = ((long)blockIdx.x * VDX_AW_NW + wave_u) * groups_per_wave;
@@ -842,18 +847,22 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
     char* const yg = reinterpret_cast<char*>(P.y);
     // per-lane byte offset inside a group: sequence b adds b * inner_stride elements
     const unsigned loff = (unsigned)(lp * P.tok_stride + q * 8) * 2u;
+    const bool tok_ok = FULL || lp < P.L;             // this lane's token exists
     const unsigned sstr = (unsigned)P.inner_stride * 2u;
     auto group_base = [&](long g) __attribute__((always_inline)) -> size_t {                       // wave-uniform: scalar unit
         const unsigned inner = (unsigned)P.inner, sg0 = (unsigned)(g * SB);
         return ((size_t)(sg0 / inner) * P.outer_stride + (size_t)(sg0 % inner) * P.inner_stride) * 2;
     };
-    uint4 xn[SB][2];
+    uint4 xn[SB][NCH];
     auto fetch = [&](long g) __attribute__((always_inline)) {
         const char* p = xg + group_base(g) + loff;
 #pragma unroll
         for (int b = 0; b < SB; ++b)
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch) xn[b][ch] = *reinterpret_cast<const uint4*>(p + b * sstr + ch * 64);
+            for (int ch = 0; ch < NCH; ++ch) {
+                xn[b][ch] = make_uint4(0u, 0u, 0u, 0u);
+                if (tok_ok) xn[b][ch] = *reinterpret_cast<const uint4*>(p + b * sstr + ch * 64);
+            }
     };
     const float escale = P.scale * 1.44269504088896f;
     // LDS read offsets of this lane (head 0): q|k|v rows t * 16 + lp of a part, chunk ch * 4 + q; Wo rows tile * 16 + lp, piece 4 h + q
@@ -869,13 +878,15 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
         for (int ch = 0; ch < 2; ++ch) wcur[ch][t] = *reinterpret_cast<const uint4*>(Wq + t * 16 * 128 + wqo[ch]);
     fetch(g_first);
     for (long g = g_first; g < g_end; ++g) {
-        uint4 xc[SB][2];
+        uint4 xc[SB][NCH];
 #pragma unroll
-        for (int b = 0; b < SB; ++b) { xc[b][0] = xn[b][0]; xc[b][1] = xn[b][1]; }
+        for (int b = 0; b < SB; ++b)
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) xc[b][ch] = xn[b][ch];
         if (g + 1 < g_end) fetch(g + 1);
-        f32x4 oacc[SB][4];                              // [sequence][tile = 2 wc + tm]
+        f32x4 oacc[SB][NTL];                            // [sequence][tile = 2 wc + tm]
 #pragma unroll
-        for (int tile = 0; tile < 4; ++tile) {
+        for (int tile = 0; tile < NTL; ++tile) {
             const float4 b4 = *reinterpret_cast<const float4*>(bl + 3 * HD + 32 * (tile >> 1) + 8 * q + 4 * (tile & 1));
 #pragma unroll
             for (int b = 0; b < SB; ++b) oacc[b][tile] = f32x4{b4.x, b4.y, b4.z, b4.w};
@@ -889,7 +900,7 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int ch = 0; ch < 2; ++ch) w[ch][t] = *reinterpret_cast<const uint4*>(base + t * 16 * 128 + wqo[ch]);
+                    for (int ch = 0; ch < NCH; ++ch) w[ch][t] = *reinterpret_cast<const uint4*>(base + t * 16 * 128 + wqo[ch]);
             };
             f32x4 aq[SB][2], ak[SB][2], av[SB][2];
             // q (fragments in wcur)
@@ -903,7 +914,7 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
             __builtin_amdgcn_sched_barrier(0);
             if (VDX_AW_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -919,7 +930,7 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
             rd(wcur, wh + 2 * HD * 128);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -930,6 +941,12 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
                 sc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
                 core_mma16<M, F8>(sc[b], ak[b][0], aq[b][0]);
                 core_mma16<M, F8>(sc[b], ak[b][1], aq[b][1]);
+            }
+            if constexpr (!FULL) {
+#pragma unroll
+                for (int b = 0; b < SB; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (4 * q + r >= P.L) sc[b][r] = -1e30f;
             }
             // v (fragments in wcur); the out-projection's fragments go to wnext
 #pragma unroll
@@ -942,11 +959,11 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
             {
                 const char* woh = Wo + woo + 16 * ((4 * h + q) ^ lp);
 #pragma unroll
-                for (int tile = 0; tile < 4; ++tile) wnext[tile >> 1][tile & 1] = *reinterpret_cast<const uint4*>(woh + tile * 8192);
+                for (int tile = 0; tile < NTL; ++tile) wnext[tile >> 1][tile & 1] = *reinterpret_cast<const uint4*>(woh + tile * 8192);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ch = 0; ch < 2; ++ch)
+            for (int ch = 0; ch < NCH; ++ch)
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -988,7 +1005,7 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
             for (int b = 0; b < SB; ++b)
                 of[b] = make_uint4(pack_bf16x2(o[b][0][0], o[b][0][1]), pack_bf16x2(o[b][0][2], o[b][0][3]), pack_bf16x2(o[b][1][0], o[b][1][1]), pack_bf16x2(o[b][1][2], o[b][1][3]));
 #pragma unroll
-            for (int tile = 0; tile < 4; ++tile)
+            for (int tile = 0; tile < NTL; ++tile)
 #pragma unroll
                 for (int b = 0; b < SB; ++b) M::mma(oacc[b][tile], wnext[tile >> 1][tile & 1], of[b]);
         }
@@ -997,7 +1014,7 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
 #pragma unroll
         for (int b = 0; b < SB; ++b)
 #pragma unroll
-            for (int wc = 0; wc < 2; ++wc) {
+            for (int wc = 0; wc < NCH; ++wc) {
                 const uint4 r = xc[b][wc];
                 const f32x4 a0 = oacc[b][2 * wc], a1 = oacc[b][2 * wc + 1];
                 uint4 w;
@@ -1005,7 +1022,7 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
                 w.y = pack_bf16x2(a0[2] + __uint_as_float(r.y << 16), a0[3] + __uint_as_float(r.y & 0xFFFF0000u));
                 w.z = pack_bf16x2(a1[0] + __uint_as_float(r.z << 16), a1[1] + __uint_as_float(r.z & 0xFFFF0000u));
                 w.w = pack_bf16x2(a1[2] + __uint_as_float(r.w << 16), a1[3] + __uint_as_float(r.w & 0xFFFF0000u));
-                *reinterpret_cast<uint4*>(yp + b * sstr + wc * 64) = w;
+                if (tok_ok) *reinterpret_cast<uint4*>(yp + b * sstr + wc * 64) = w;
             }
     }
 }
@@ -1014,15 +1031,12 @@ __global__ __launch_bounds__(64 * VDX_AW_NW) void attention_w_kernel(const AttnA
 #define VDX_ATTN_W 1
 #endif
 static bool attn_w_eligible(const AttnArgs& a) {
-    return VDX_ATTN_W && a.io_bf16 && a.C == 64 && a.CPad == 64 && a.HDPad == 256 && a.heads == 8 && a.L == 16 && a.inner % 4 == 0 && a.nseq % 4 == 0 &&
-           a.nseq >= 256 && a.nseq < (1L << 29) && 3 * a.inner_stride + 15 * a.tok_stride + a.C < (1L << 30);
+    return VDX_ATTN_W && a.io_bf16 && (a.C == 64 || a.C == 32) && a.CPad == 64 && a.HDPad == 256 && a.heads == 8 && a.L >= 1 && a.L <= 16 && a.inner % 4 == 0 &&
+           a.nseq % 4 == 0 && a.nseq >= 256 && a.nseq < (1L << 29) && 3 * a.inner_stride + 15 * a.tok_stride + a.C < (1L << 30);
 }
 template <bool F8>
 static hipError_t launch_attn_w(const AttnArgs& a, hipStream_t st) {
-    const size_t lds = 3 * 256 * 128 + 64 * 512 + (3 * 256 + 64) * 4;
-    auto kfn = attention_w_kernel<F8>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
+    const size_t lds = 3 * 256 * 128 + (size_t)a.C * 512 + (3 * 256 + 64) * 4;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
     const long ngroups = a.nseq / VDX_AW_SB;
@@ -1030,9 +1044,15 @@ static hipError_t launch_attn_w(const AttnArgs& a, hipStream_t st) {
     const int gpw = (int)((ngroups + waves - 1) / waves);
     const long blocks = (ngroups + (long)gpw * VDX_AW_NW - 1) / ((long)gpw * VDX_AW_NW);
     const AttnWork aw = attn_work(a, 2, true);
-    LaunchScope ls(st, "attention_w_kernel", aw.flops, aw.bytes, "<fp8 %d> C%d L%d nseq%ld", (int)F8, a.C, a.L, a.nseq);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(64 * VDX_AW_NW), lds, st, a, gpw, ngroups);
-    return hipGetLastError();
+    auto go = [&](auto kfn) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        LaunchScope ls(st, "attention_w_kernel", aw.flops, aw.bytes, "<fp8 %d> C%d L%d nseq%ld", (int)F8, a.C, a.L, a.nseq);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)blocks), dim3(64 * VDX_AW_NW), lds, st, a, gpw, ngroups);
+        return hipGetLastError();
+    };
+    if (a.C == 64) return a.L == 16 ? go(attention_w_kernel<F8, 64, true>) : go(attention_w_kernel<F8, 64, false>);
+    return a.L == 16 ? go(attention_w_kernel<F8, 32, true>) : go(attention_w_kernel<F8, 32, false>);
 }
 
 // ---- wide levels (C >= 256): one workgroup per (head, sequence chunk) ----------------------------------------------------------------
@@ -1275,6 +1295,7 @@ static hipError_t launch_attn_m(const AttnArgs& a, hipStream_t st) {
         const int nkt = a.CPad / Mma<MODE>::KT;
         if constexpr (MODE == MODE_BF16) {
             if (a.fp8_core) {                                 // fp8 QK^T / PV (vdx_set_attention_fp8)
+                if (attn_w_eligible(a)) return launch_attn_w<true>(a, st);
                 if (a.io_bf16 && a.C == 64) return launch_attn_h8_t<MODE, 1, 1, 2, true, true>(a, st);
                 if (a.io_bf16 && a.C == 128) return launch_attn_h8_t<MODE, 2, 1, 4, true, true>(a, st);
                 if (a.C == 64 && nkt == 1) return launch_attn_h8_t<MODE, 1, 1, 2, false, true>(a, st);

@@ -61,7 +61,7 @@ template <int GEO> struct WsGeo {
 };
 
 template <int GEO, bool PRO>
-__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, const int tiles_per_range, const int total_tiles, const int nct) {
+__global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, const int tiles_per_range, const int total_tiles, const int nct, const int pin) {
     using M = Mma<MODE_BF16>;
     using G = WsGeo<GEO>;
     constexpr bool WF = G::WF;
@@ -83,9 +83,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
     const int r = lane & 15, q = lane >> 4;
     const int wc = wave & 1, wpx = wave >> 1;
     // ids i, i + 8, ... share an XCD: the nct output-channel tiles of one pixel range are consecutive slots of one XCD
+    // pin (launcher: the nct weight tiles together exceed an XCD's 4 MB L2, e.g. 512 -> 512: 4 x 1.18 MB): output-channel tile j lives on
+    // the 8 / nct XCDs with xcd % nct == j, so its weights stay L2-resident while the (4.5 x smaller) input tiles are fetched once per XCD
+    // instead of once -- with every XCD cycling through all nct tiles the weight stream missed L2 on every pixel tile
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int j = slot % nct;
-    const int range = (slot / nct) * 8 + xcd;
+    const int j = pin ? xcd % nct : slot % nct;
+    const int range = pin ? slot * (8 / nct) + xcd / nct : (slot / nct) * 8 + xcd;
     const int t0 = range * tiles_per_range, t1 = min(t0 + tiles_per_range, total_tiles);
     if (t0 >= t1) return;
     const int tiles_x = WF ? 1 : P.W / 16, tiles_pf = WF ? 1 : tiles_x * (P.H / 16);     // GEO 0: tiles per frame
@@ -726,7 +729,12 @@ hipError_t launch_conv3x3_ws(const ConvArgs& a, hipStream_t st) {
     auto go = [&](auto kfn) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a, tpr, total, nct);
+#ifndef VDX_WS_PIN_MB
+#define VDX_WS_PIN_MB 3        // pin output-channel tiles to XCDs when their weights together exceed this many MB (0: never)
+#endif
+        const size_t wbytes = (size_t)9 * a.Cout * a.CinPad * 2;
+        const int pin = (VDX_WS_PIN_MB > 0 && nct > 1 && wbytes > (size_t)VDX_WS_PIN_MB * 1024 * 1024) ? 1 : 0;
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, a, tpr, total, nct, pin);
         return hipGetLastError();
     };
     if (geo == 0) return a.pro ? go(conv3x3_ws_kernel<0, true>) : go(conv3x3_ws_kernel<0, false>);
