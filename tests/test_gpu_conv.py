@@ -184,7 +184,7 @@ WS_CASES = [
     (4, 16, 16, 128, 128, 256),        # level-2 shape with a two-pointer concat input, two output-channel tiles per range
     (8, 16, 8, 512, 0, 512),           # level-3 / mid shape: four whole 8 x 8 frames per tile, four output-channel tiles, ring of 3
     (8, 8, 8, 256, 0, 128),            # F = 8: two tiles per sample
-    (16, 16, 8, 512, 512, 256),        # ups.0 block1: 1024 -> 256 on a concat input; 4.7 MB of weights: output-channel tiles pinned to XCDs (as 512 -> 512 above)
+    (16, 16, 8, 512, 512, 256),        # ups.0 block1: 1024 -> 256 on a concat input, two output-channel tiles, 16 K chunks
 ]
 
 

@@ -13,7 +13,9 @@ if [ "$part" = a ] || [ "$part" = all ]; then
 fi
 if [ "$part" = b ] || [ "$part" = all ]; then
   PMC_GROUPS="0 3 8" bash tools/pmc_passes.sh "$tag" tools/bench_short.py > "$out/${tag}_pmc_raw.txt" 2>&1
-  python3 tools/shape_table.py "$out/pmc_$tag" "$out/prof_step_$tag/seq.json" --pmc 32 > "$out/${tag}_pmc_step.md" 2>&1; head -5 "$out/${tag}_pmc_step.md"
+  # (part b may run on another box than part a: gpurun_out/ does not travel, the committed launch sequence does)
+  seq="$out/prof_step_$tag/seq.json"; [ -f "$seq" ] || seq="$root/profiles/${tag}_launch_seq.json"
+  python3 tools/shape_table.py "$out/pmc_$tag" "$seq" --pmc 32 > "$out/${tag}_pmc_step.md" 2>&1; head -5 "$out/${tag}_pmc_step.md"
   bash tools/prof_train.sh "$tag" > "$out/${tag}_train.txt" 2>&1
   python3 tools/ktrace.py "$out/prof_train_$tag" 6 70 >> "$out/${tag}_train.txt" 2>&1; head -4 "$out/${tag}_train.txt"
   PMC_GROUPS="0 3 8" bash tools/pmc_passes.sh "${tag}train" tools/train_bench.py > "$out/${tag}_pmc_train_raw.txt" 2>&1

@@ -83,9 +83,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
     const int r = lane & 15, q = lane >> 4;
     const int wc = wave & 1, wpx = wave >> 1;
     // ids i, i + 8, ... share an XCD: the nct output-channel tiles of one pixel range are consecutive slots of one XCD
-    // pin (launcher: the nct weight tiles together exceed an XCD's 4 MB L2, e.g. 512 -> 512: 4 x 1.18 MB): output-channel tile j lives on
-    // the 8 / nct XCDs with xcd % nct == j, so its weights stay L2-resident while the (4.5 x smaller) input tiles are fetched once per XCD
-    // instead of once -- with every XCD cycling through all nct tiles the weight stream missed L2 on every pixel tile
+    // pin (an experiment, off: VDX_WS_PIN_MB): output-channel tile j lives on the 8 / nct XCDs with xcd % nct == j, so that weight tiles which
+    // together exceed an XCD's 4 MB L2 (512 -> 512: 4 x 1.18 MB) stay L2-resident, at the price of fetching every input tile once per XCD
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int j = pin ? xcd % nct : slot % nct;
     const int range = pin ? slot * (8 / nct) + xcd / nct : (slot / nct) * 8 + xcd;
@@ -730,7 +729,9 @@ hipError_t launch_conv3x3_ws(const ConvArgs& a, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
 #ifndef VDX_WS_PIN_MB
-#define VDX_WS_PIN_MB 3        // pin output-channel tiles to XCDs when their weights together exceed this many MB (0: never)
+#define VDX_WS_PIN_MB 0        // pin output-channel tiles to XCDs when their weights together exceed this many MB (0: never).  Measured with 3 (r03, 512 -> 512 at 8 x 8):
+                               // same time (251 vs 250 us plain, 307 vs 317 with the prologue) for MORE HBM traffic (401-454 vs 290-326 MB per launch: the input tiles
+                               // are then fetched by four XCDs) -- the Infinity Cache serves the weight stream as fast as the L2 does; off
 #endif
         const size_t wbytes = (size_t)9 * a.Cout * a.CinPad * 2;
         const int pin = (VDX_WS_PIN_MB > 0 && nct > 1 && wbytes > (size_t)VDX_WS_PIN_MB * 1024 * 1024) ? 1 : 0;

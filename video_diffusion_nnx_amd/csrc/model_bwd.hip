@@ -24,6 +24,7 @@ struct Bwd {
     float* act; float* temb; float* ss; float* ss_lin; double* stats;
     // backward workspace views
     std::vector<LevelBufs> lv; float* gr; float* S; float* dss; float* dtemb; float* normscr; float* sla_a;
+    float* part_side; float* part_main;             // slots of the deterministic accumulations (WG_PART_FLOATS each): one per stream, used in stream order
     float* slot(int s) const { return act + (size_t)m->slots[s].offset_per_sample * B; }
     double* stat(int i) const { return stats + (size_t)i * B * GN_SLOTS * m->cfg.resnet_groups * 2; }
     long pix(int lvl) const { const long s = m->cfg.image_size >> lvl; return (long)m->cfg.num_frames * s * s; }
@@ -106,6 +107,7 @@ void wgrad(Bwd& b, const float* x0, int c0, const float* x1, int c1, const float
     a.kind = kind; a.kh = a.kw = kind ? 4 : k; a.stride = kind ? 1 : stride;
     a.bf16_mma = (b.m->mode == MODE_BF16);
     if (in_stats) { a.x0_bf16 = (b.m->mode == MODE_BF16); a.pro = 1; a.in_stats = in_stats; a.gamma = gamma; a.beta = beta; a.groups = b.m->cfg.resnet_groups; a.ss = ss; a.ss_stride = ss_stride; }
+    a.part = b.part_side; a.part_cap = WG_PART_FLOATS;             // (every weight gradient runs on the side stream, in order)
     b.ok(launch_conv_wgrad(a, b.side()));
     b.side_done(dy);
 }
@@ -127,6 +129,7 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     t.r = rsrc; t.r_bf16 = b.a16; t.ln_gamma = b.p + r.n2_s; t.dr = L.t2; t.d_ln_gamma = b.grads + r.n2_s; t.d_ln_beta = b.grads + r.n2_b;
     // R at a fixed offset of the scratch: zeroed once per backward, the finalize pass leaves it zero again
     t.G = b.normscr; t.R = b.normscr + (size_t)b.B * 64; t.C = r.cout; t.batch = b.B; t.pix_per_sample = b.pix(lvl);
+    t.dgp = b.part_main;
     b.ok(launch_norm_bwd(t, b.writes(L.t1, L.t2)));
     // 2. conv2: y2 = conv(SiLU(GN1(y1)*(1+s)+sh)); the weight gradients that only need the tail's outputs go to the side stream now
     const float* ssrow = r.has_mlp ? b.ss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
@@ -140,6 +143,7 @@ void res_bwd(Bwd& b, const ResP& r, const float* g, const float* x0, int c0, con
     q.ss = ssrow; q.ss_stride = 2 * r.cout; q.d_gamma = b.grads + r.b1_gs; q.d_beta = b.grads + r.b1_gb;
     q.dss = r.has_mlp ? b.dss + (size_t)m->ss_layers[r.ss_index].out_off * b.B : nullptr;
     q.G = b.normscr; q.R = b.normscr + (size_t)b.B * 64; q.C = r.cout; q.batch = b.B; q.pix_per_sample = b.pix(lvl);
+    q.dgp = b.part_main;
     b.ok(launch_norm_bwd(q, b.writes(L.t4)));                                                           // t4 = dL/d(y1) (not t1: conv2's weight gradient may still be reading it)
     // 4. conv1 + residual branch
     wgrad(b, x0, c0, x1, c1, L.t4, r.cout, r.b1_w, r.b1_b, lvl, 0, 3, 1, nullptr, nullptr, nullptr, nullptr, 0, d16);
@@ -176,6 +180,7 @@ void wgrad1x1(Bwd& b, const float* x, int cin, const float* dy, int cout, long w
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
     a.bf16_mma = (b.m->mode == MODE_BF16);
+    a.part = b.part_side; a.part_cap = WG_PART_FLOATS;             // (every weight gradient runs on the side stream, in order)
     b.ok(launch_conv_wgrad(a, b.side()));
     b.side_done(b.S, dy);                                          // x = O lives in the attention scratch
 }
@@ -191,6 +196,7 @@ void wgrad1x1_qkv(Bwd& b, const float* x, int cin, const float* dqkv, int hd, co
     a.NF = b.B * b.m->cfg.num_frames; a.F = b.m->cfg.num_frames; a.H = a.W = b.size(lvl);
     a.kind = 0; a.kh = a.kw = 1; a.stride = 1;
     a.bf16_mma = (b.m->mode == MODE_BF16);
+    a.part = b.part_side; a.part_cap = WG_PART_FLOATS;             // (every weight gradient runs on the side stream, in order)
     b.ok(launch_conv_wgrad(a, b.side()));
     b.side_done(b.S);                                              // dq | dk | dv live in the attention scratch
 }
@@ -268,7 +274,7 @@ float* other(const LevelBufs& L, const float* cur) { return cur == L.ga ? L.gb :
 // all-reduces a bucket as soon as its last stage has been enqueued); d(temb) accumulates across stages and is consumed by the stem.
 void ss_bwd(Bwd& b, int first, int count) {
     if (first < 0 || count <= 0) return;
-    b.ok(launch_resblock_ss_bwd(b.p, b.grads, b.temb, b.m->d_ss_layers + first, count, b.ss_lin, b.dss, b.dtemb, b.m->temb_dim, b.B, b.writes(nullptr)));
+    b.ok(launch_resblock_ss_bwd(b.p, b.grads, b.temb, b.m->d_ss_layers + first, count, b.ss_lin, b.dss, b.dtemb, b.m->temb_dim, b.B, b.writes(nullptr), b.part_main, WG_PART_FLOATS));
 }
 
 }  // namespace
@@ -305,6 +311,7 @@ size_t model_bwd_workspace_bytes(const Model* m, int B) {
     fl += al((size_t)m->temb_dim * B);                             // dtemb
     fl += al(norm_scratch_floats(m, B));                           // norm scratch
     fl += al(sla_bwd_scratch_floats(B * m->cfg.num_frames, m->cfg.attn_heads));
+    fl += 2 * al(WG_PART_FLOATS);                                   // deterministic accumulation slots: side stream, main stream
     return fl * 4;
 }
 
@@ -353,7 +360,9 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
         b.dss = w; w += al((size_t)m->ss_floats_per_sample * B);
         b.dtemb = w; w += al((size_t)m->temb_dim * B);
         b.normscr = w; w += al(norm_scratch_floats(m, B));
-        b.sla_a = w;
+        b.sla_a = w; w += al(sla_bwd_scratch_floats(B * c.num_frames, c.attn_heads));
+        b.part_side = w; w += al(WG_PART_FLOATS);
+        b.part_main = w;
     }
     hipError_t e;
     if (!state->side) {
@@ -372,7 +381,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             VDX_E(hipMemsetAsync(b.dtemb, 0, (size_t)m->temb_dim * B * 4, st));
             // head: out = conv1x1(fin(concat(x_up, r)))
             const Level& U = m->ups[nl - 1];
-            VDX_E(launch_final_conv_bwd(b.slot(m->fin.s_out), d_out, params + m->fin_w, b.lv[0].ga, grads + m->fin_w, grads + m->fin_b, pix0, c.dim, m->out_dim, b.a16, b.writes(b.lv[0].ga)));
+            VDX_E(launch_final_conv_bwd(b.slot(m->fin.s_out), d_out, params + m->fin_w, b.lv[0].ga, grads + m->fin_w, grads + m->fin_b, pix0, c.dim, m->out_dim, b.a16, b.writes(b.lv[0].ga), b.part_main, WG_PART_FLOATS));
             res_bwd(b, m->fin, b.lv[0].ga, b.slot(U.s_attn), U.cout, b.slot(m->s_init_attn), m->init_dim, 0, b.lv[0].gb, b.gr);
             g = b.lv[0].gb;
         } else if (stage >= nl + 2) {
@@ -436,7 +445,7 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             float* o = other(LB, g);
             attn_bwd(b, m->init_attn, g, b.slot(m->s_init), 0, true, o); g = o;
             VDX_E(launch_init_conv_wgrad(x, g, grads + m->init_w, grads + m->init_b, B, c.channels, c.num_frames, c.image_size, c.image_size,
-                                         m->init_dim, c.init_kernel_size, b.side()));
+                                         m->init_dim, c.init_kernel_size, b.side(), b.part_side, WG_PART_FLOATS));
             b.side_done(g);
             TimeMlpArgs t;
             memset(&t, 0, sizeof(t));

@@ -189,19 +189,41 @@ __global__ __launch_bounds__(256) void norm_bwd_finalize_kernel(NormBwdArgs P, i
 #pragma unroll
         for (int k = 0; k < 4; ++k) red[k][tid] = a[k];
         __syncthreads();
+        float v1 = 0.f, v2 = 0.f;
         if (sl == 0 && mine) {
             float R0 = 0.f, R1 = 0.f, q0 = 0.f, q1 = 0.f;
             for (int k = 0; k < NS; ++k) { R0 += red[0][k * CW + cl]; R1 += red[1][k * CW + cl]; q0 += red[2][k * CW + cl]; q1 += red[3][k * CW + cl]; }
             float sc = 1.f;
             if (P.ss) sc = P.ss[(size_t)b * P.ss_stride + c] + 1.f;
             const float ga = P.gamma[c], be = P.beta[c];
-            atomicAdd(P.d_gamma + c, sc * R1);
-            atomicAdd(P.d_beta + c, sc * R0);
-            if (P.r) { atomicAdd(P.d_ln_gamma + c, q0); atomicAdd(P.d_ln_beta + c, q1); }
+            if (P.dgp) {                                       // deterministic mode: per-sample rows, added over the samples in order by the apply pass
+                float* d = P.dgp + (size_t)b * 4 * C;
+                d[c] = sc * R1; d[C + c] = sc * R0;
+                if (P.r) { d[2 * C + c] = q0; d[3 * C + c] = q1; }
+            } else {
+                atomicAdd(P.d_gamma + c, sc * R1);
+                atomicAdd(P.d_beta + c, sc * R0);
+                if (P.r) { atomicAdd(P.d_ln_gamma + c, q0); atomicAdd(P.d_ln_beta + c, q1); }
+            }
             if (P.dss) { P.dss[(size_t)b * 2 * C + c] = ga * R1 + be * R0; P.dss[(size_t)b * 2 * C + C + c] = R0; }
-            const int gl = c / cpg - g0;
-            atomicAdd(&s1[gl], sc * ga * R0);
-            atomicAdd(&s2[gl], sc * ga * R1);
+            v1 = sc * ga * R0; v2 = sc * ga * R1;
+            if (!P.dgp) {
+                const int gl = c / cpg - g0;
+                atomicAdd(&s1[gl], v1);
+                atomicAdd(&s2[gl], v2);
+            }
+        }
+        if (P.dgp) {                                           // (uniform) the groups' sums over their channels, one thread per group, in channel order
+            __syncthreads();
+            if (sl == 0 && mine) { red[0][cl] = v1; red[1][cl] = v2; }
+            __syncthreads();
+            if (tid < ngl) {
+                const int lo = (g0 + tid) * cpg - c0 - cc;
+                for (int i = 0; i < cpg; ++i) {
+                    const int l = lo + i;
+                    if (l >= 0 && l < CW && cc + l < CT && c0 + cc + l < C) { s1[tid] += red[0][l]; s2[tid] += red[1][l]; }
+                }
+            }
         }
     }
     __syncthreads();
@@ -220,6 +242,17 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs P) {
     NbTables T{mu, rsd, ta, td};
     nb_build_tables(P, b, gm, T);
     if (tid < 2 * P.groups) gs[tid] = P.G[(size_t)b * P.groups * 2 + tid];
+    if (P.dgp && blockIdx.x == 0 && blockIdx.y == 0) {
+        // deterministic mode: the parameter gradients = the finalize pass's per-sample rows added in sample order (one workgroup, once)
+        const int nq = P.r ? 4 : 2;
+        for (int i = tid; i < nq * C; i += 256) {
+            const int qy = i / C, c = i - qy * C;
+            float t = 0.f;
+            for (int bb = 0; bb < P.batch; ++bb) t += P.dgp[((size_t)bb * 4 + qy) * C + c];
+            float* dst = qy == 0 ? P.d_gamma : qy == 1 ? P.d_beta : qy == 2 ? P.d_ln_gamma : P.d_ln_beta;
+            dst[c] += t;
+        }
+    }
     __syncthreads();
     const int cpg = C / P.groups;
     const int LPP = P.lpp, ppb = 256 / LPP, sub = tid % LPP, pl = tid / LPP;

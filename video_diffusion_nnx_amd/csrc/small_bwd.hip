@@ -23,8 +23,9 @@ __global__ __launch_bounds__(256) void final_conv_dx_kernel(const float* __restr
 }
 
 // final conv: dW[c][co] += sum_pix x[pix][c] dout[pix][co] ; db[co] += sum_pix dout[pix][co]     (D <= 256, Cout <= 4)
+// part (deterministic mode): this workgroup's sums go to part[blockIdx.x][D * Cout] and, behind all of those, [blockIdx.x][Cout]
 __global__ __launch_bounds__(256) void final_conv_dw_kernel(const float* __restrict__ x, const float* __restrict__ dout, float* __restrict__ dW,
-                                                            float* __restrict__ db, long npix, int D, int Cout, int x_bf16) {
+                                                            float* __restrict__ db, long npix, int D, int Cout, int x_bf16, float* __restrict__ part) {
     __shared__ float red[256 * 4];
     const int c = threadIdx.x % D, pl = threadIdx.x / D, PL = 256 / D;
     float acc[4] = {0.f, 0.f, 0.f, 0.f}, accb[4] = {0.f, 0.f, 0.f, 0.f};
@@ -54,15 +55,27 @@ __global__ __launch_bounds__(256) void final_conv_dw_kernel(const float* __restr
         if (pl == 0) {
             float t = 0.f;
             for (int k = 0; k < PL; ++k) t += red[k * D + c];
-            atomicAdd(dW + (size_t)c * Cout + co, t);
+            if (part) part[(size_t)blockIdx.x * D * Cout + (size_t)c * Cout + co] = t;
+            else atomicAdd(dW + (size_t)c * Cout + co, t);
         }
-        if (c == 0 && pl < PL) atomicAdd(db + co, accb[co]);
+        if (!part) { if (c == 0 && pl < PL) atomicAdd(db + co, accb[co]); }
+        else {
+            __syncthreads();
+            if (c == 0 && pl < PL) red[pl] = accb[co];
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float t = 0.f;
+                for (int k = 0; k < PL; ++k) t += red[k];
+                part[(size_t)gridDim.x * D * Cout + (size_t)blockIdx.x * Cout + co] = t;
+            }
+        }
     }
 }
 
 // init conv weight gradient: x external [B,Cin,F,H,W]; dy channel-last [B,F,H,W,Cout]; dW Flax (K,K,Cin,Cout); db [Cout]
+// part (deterministic mode): slot = (frame, tile); dW slots [slot][K * K * Cin * Cout], bias slots behind them [slot][Cout]
 __global__ __launch_bounds__(256) void init_conv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dW,
-                                                              float* __restrict__ db, int B, int Cin, int F, int H, int W, int Cout, int K) {
+                                                              float* __restrict__ db, int B, int Cin, int F, int H, int W, int Cout, int K, float* __restrict__ part) {
     extern __shared__ float sm[];
     const int pad = K / 2, TW = 16 + K - 1;
     float* xs = sm;                               // [Cin][TW][TW]
@@ -88,12 +101,16 @@ __global__ __launch_bounds__(256) void init_conv_wgrad_kernel(const float* __res
         const int ky = tap / K, kx = tap % K;
         float acc = 0.f;
         for (int p = 0; p < 256; ++p) acc = fmaf(xs[(c * TW + (p >> 4) + ky) * TW + (p & 15) + kx], ds[p * 17 + j], acc);
-        if (co0 + j < Cout) atomicAdd(dW + ((size_t)tap * Cin + c) * Cout + co0 + j, acc);
+        if (co0 + j < Cout) {
+            if (part) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * ((size_t)K * K * Cin * Cout) + ((size_t)tap * Cin + c) * Cout + co0 + j] = acc;
+            else atomicAdd(dW + ((size_t)tap * Cin + c) * Cout + co0 + j, acc);
+        }
     }
     if (threadIdx.x < 16 && co0 + threadIdx.x < Cout) {
         float t = 0.f;
         for (int p = 0; p < 256; ++p) t += ds[p * 17 + threadIdx.x];
-        atomicAdd(db + co0 + threadIdx.x, t);
+        if (part) part[(size_t)gridDim.y * gridDim.x * ((size_t)K * K * Cin * Cout) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * Cout + co0 + threadIdx.x] = t;
+        else atomicAdd(db + co0 + threadIdx.x, t);
     }
 }
 
@@ -151,9 +168,10 @@ __global__ __launch_bounds__(256) void resblock_ss_bwd_kernel(const float* __res
 // second half of the time-MLP backward, parallel over (layer, KB rows of the Linear): with dlin from the kernel above
 //   dW[k][n] += sum_b SiLU(temb[b][k]) dlin[b][n]          (coalesced over n)
 //   dtemb[b][k] += SiLU'(temb[b][k]) sum_n dlin[b][n] W[k][n]   (workgroup reduction over n, one atomic per (b, k))
+// part (deterministic mode): layer l writes its d(temb) contribution to part[l][B][temb_dim]; the launcher adds the layers in order
 __global__ __launch_bounds__(256) void resblock_ss_bwd_w_kernel(const float* __restrict__ params, float* __restrict__ grads, const float* __restrict__ temb,
                                                                 const SsLayer* __restrict__ layers, const float* __restrict__ dss_base,
-                                                                float* __restrict__ dtemb, int temb_dim, int B, int SS_KB) {
+                                                                float* __restrict__ dtemb, int temb_dim, int B, int SS_KB, float* __restrict__ part) {
     __shared__ float red[4];
     const int tid = threadIdx.x;
     const SsLayer L = layers[blockIdx.x];
@@ -176,7 +194,11 @@ __global__ __launch_bounds__(256) void resblock_ss_bwd_w_kernel(const float* __r
             __syncthreads();
             if ((tid & 63) == 0) red[tid >> 6] = acc;
             __syncthreads();
-            if (tid == 0) atomicAdd(dtemb + (size_t)b * temb_dim + k, (red[0] + red[1] + red[2] + red[3]) * dsilu2_f(temb[(size_t)b * temb_dim + k]));
+            if (tid == 0) {
+                const float v = (red[0] + red[1] + red[2] + red[3]) * dsilu2_f(temb[(size_t)b * temb_dim + k]);
+                if (part) part[((size_t)blockIdx.x * B + b) * temb_dim + k] = v;
+                else atomicAdd(dtemb + (size_t)b * temb_dim + k, v);
+            }
         }
     }
 }
@@ -284,26 +306,37 @@ __global__ __launch_bounds__(256) void time_mlp_bwd_kernel(TimeMlpArgs P, const 
         }
 }
 
-hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, int x_bf16, hipStream_t st) {
+hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, int x_bf16, hipStream_t st, float* part, size_t part_cap) {
     if (D > 256 || Cout > 4) return hipErrorInvalidValue;
     const int blocks = (int)std::max<long>(1, std::min<long>((npix * (D / 4) + 255) / 256, 4096));
     hipLaunchKernelGGL(final_conv_dx_kernel, dim3(blocks), dim3(256), 0, st, dout, w, dx, npix, D, Cout);
     const int PL = 256 / D;
     const int b2 = (int)std::max<long>(1, std::min<long>((npix + PL - 1) / PL, 512));
-    hipLaunchKernelGGL(final_conv_dw_kernel, dim3(b2), dim3(256), 0, st, x, dout, dW, db, npix, D, Cout, x_bf16);
-    return hipGetLastError();
+    if (part && (size_t)b2 * (D + 1) * Cout > part_cap) part = nullptr;
+    hipLaunchKernelGGL(final_conv_dw_kernel, dim3(b2), dim3(256), 0, st, x, dout, dW, db, npix, D, Cout, x_bf16, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !part) return e;
+    e = launch_slot_sum(part, b2, (size_t)D * Cout, (long)D * Cout, Cout, 0, dW, nullptr, nullptr, st);
+    if (e != hipSuccess) return e;
+    return launch_slot_sum(part + (size_t)b2 * D * Cout, b2, (size_t)Cout, Cout, Cout, 0, db, nullptr, nullptr, st);
 }
 
-hipError_t launch_init_conv_wgrad(const float* x, const float* dy, float* dW, float* db, int B, int Cin, int F, int H, int W, int Cout, int K, hipStream_t st) {
+hipError_t launch_init_conv_wgrad(const float* x, const float* dy, float* dW, float* db, int B, int Cin, int F, int H, int W, int Cout, int K, hipStream_t st, float* part, size_t part_cap) {
     const int TW = 16 + K - 1;
     dim3 grid(((W + 15) / 16) * ((H + 15) / 16), B * F, (Cout + 15) / 16);
     const size_t lds = ((size_t)Cin * TW * TW + 256 * 17) * 4;
-    hipLaunchKernelGGL(init_conv_wgrad_kernel, grid, dim3(256), lds, st, x, dy, dW, db, B, Cin, F, H, W, Cout, K);
-    return hipGetLastError();
+    const size_t E = (size_t)K * K * Cin * Cout, nslots = (size_t)grid.x * grid.y;
+    if (part && nslots * (E + Cout) > part_cap) part = nullptr;
+    hipLaunchKernelGGL(init_conv_wgrad_kernel, grid, dim3(256), lds, st, x, dy, dW, db, B, Cin, F, H, W, Cout, K, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !part) return e;
+    e = launch_slot_sum(part, (int)nslots, E, (long)E, Cout, 0, dW, nullptr, nullptr, st);
+    if (e != hipSuccess) return e;
+    return launch_slot_sum(part + nslots * E, (int)nslots, (size_t)Cout, Cout, Cout, 0, db, nullptr, nullptr, st);
 }
 
 hipError_t launch_resblock_ss_bwd(const float* params, float* grads, const float* temb, const SsLayer* layers, int nlayers, const float* lin_base,
-                                  float* dss_base, float* dtemb, int temb_dim, int B, hipStream_t st) {
+                                  float* dss_base, float* dtemb, int temb_dim, int B, hipStream_t st, float* part, size_t part_cap) {
     const size_t lds = ((size_t)B * temb_dim + 16) * 4;
     auto kfn = resblock_ss_bwd_kernel;
     if (lds > 64 * 1024) {
@@ -316,9 +349,12 @@ hipError_t launch_resblock_ss_bwd(const float* params, float* grads, const float
     // rows of the Linear per workgroup: the per-stage launches of the staged backward cover 2 layers each (data-parallel bucket
     // readiness, model_bwd.hip ss_bwd), so they take one row per workgroup to still fill the chip
     const int kb = nlayers >= 8 ? 8 : 1;
+    if (part && (size_t)nlayers * B * temb_dim > part_cap) part = nullptr;
     hipLaunchKernelGGL(resblock_ss_bwd_w_kernel, dim3(nlayers, (temb_dim + kb - 1) / kb), dim3(256), 0, st, params, grads, temb, layers,
-                       dss_base, dtemb, temb_dim, B, kb);
-    return hipGetLastError();
+                       dss_base, dtemb, temb_dim, B, kb, part);
+    e = hipGetLastError();
+    if (e != hipSuccess || !part) return e;
+    return launch_slot_sum(part, nlayers, (size_t)B * temb_dim, (long)B * temb_dim, temb_dim, 0, dtemb, nullptr, nullptr, st);
 }
 
 hipError_t launch_time_mlp_bwd(const TimeMlpArgs& a, const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, float* dnull, int B, hipStream_t st) {

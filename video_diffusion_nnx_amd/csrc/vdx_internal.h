@@ -176,6 +176,11 @@ struct WgradArgs {
     int dy_bf16;                                           // dy stored as bf16 (backward intermediates of bf16 mode)
     int split; float* dW1; float* dW2; float* db1; float* db2;   // split > 0: dY column block co / split goes to (dW, dW1, dW2)[co / split], each [taps][Cin][split]
     int bf16_mma;                                          // bf16 MFMA operands (bf16 mode) instead of exact f32
+    // deterministic accumulation (round 3): when `part` is set and large enough, every workgroup STORES its partial tile into its own slot
+    // part[slot][taps][Cin][Cout] (bias sums: behind them, [slot][Cout]) and a finalize pass adds the slots in a fixed order -- no atomics,
+    // so two runs give bit-identical gradients.  Without scratch (the block-level entry points) the kernels add with float atomics.
+    float* part; size_t part_cap;                          // scratch and its capacity in floats, or null / 0
+    float* part_b; long part_E;                            // completed by the launcher: bias slots, floats per dW slot
     // completed by the launcher
     int taps, sa, sb, ext, halo, Hm, Wm, Hy, Wy, PH, PW, co_tiles;
     unsigned m_iw, m_bw;                                   // magic multipliers (div_magic) of the staged window widths
@@ -184,7 +189,11 @@ struct WgradArgs {
 hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st);
 struct PackJob;
 hipError_t launch_pack_jobs(int mode, const float* params, void* dst_base, const PackJob* d_jobs, int njobs, hipStream_t st);
-hipError_t launch_colsum(const float* x, float* out, long rows, int C, hipStream_t st);
+hipError_t launch_colsum(const float* x, float* out, long rows, int C, hipStream_t st, float* part = nullptr, size_t part_cap = 0);
+// dst[e] (+= the split targets: column block co / split of a [rows][Cout] layout goes to d0 / d1 / d2) += sum over slots k < nslots, in
+// order, of part[k * slot_stride + e], e < E: the second half of every deterministic accumulation of the backward
+hipError_t launch_slot_sum(const float* part, int nslots, size_t slot_stride, long E, int Cout, int split, float* d0, float* d1, float* d2, hipStream_t st);
+constexpr size_t WG_PART_FLOATS = (size_t)12 << 20;        // scratch per stream for the slots (48 MB; a launch that needs more falls back to atomics)
 hipError_t launch_add_inplace(float* y, const float* x, long n, hipStream_t st);
 
 // Backward of  act = SiLU((gamma*GN(y)+beta)*(1+s)+sh)  [+ LayerNorm_C(r) branch of the block tail]; channel-last [B][pix][C]
@@ -200,6 +209,7 @@ struct NormBwdArgs {
     const float* r; const float* ln_gamma; float* dr; float* d_ln_gamma; float* d_ln_beta;   // LN branch (tail) or nulls
     float* R; float* G;                                           // scratch: per-workgroup partial sums [B][nwg][4][C] (written, never accumulated), [B][groups][2]
     int nwg;                                                      // workgroups per sample of the reduce pass (completed by the launcher)
+    float* dgp;                                                   // deterministic mode: scratch [batch][4][C] for the per-sample parameter-gradient rows (or null: float atomics)
     int C, batch; long pix_per_sample;
     int lpp;
 };
@@ -238,10 +248,10 @@ struct SlaBwdArgs {
 size_t sla_bwd_scratch_floats(int NF, int heads);
 hipError_t launch_sla_bwd(const SlaBwdArgs& a, hipStream_t st);
 
-hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, int x_bf16, hipStream_t st);
-hipError_t launch_init_conv_wgrad(const float* x, const float* dy, float* dW, float* db, int B, int Cin, int F, int H, int W, int Cout, int K, hipStream_t st);
+hipError_t launch_final_conv_bwd(const float* x, const float* dout, const float* w, float* dx, float* dW, float* db, long npix, int D, int Cout, int x_bf16, hipStream_t st, float* part = nullptr, size_t part_cap = 0);
+hipError_t launch_init_conv_wgrad(const float* x, const float* dy, float* dW, float* db, int B, int Cin, int F, int H, int W, int Cout, int K, hipStream_t st, float* part = nullptr, size_t part_cap = 0);
 hipError_t launch_resblock_ss_bwd(const float* params, float* grads, const float* temb, const SsLayer* layers, int nlayers, const float* lin_base,
-                                  float* dss_base, float* dtemb, int temb_dim, int B, hipStream_t st);
+                                  float* dss_base, float* dtemb, int temb_dim, int B, hipStream_t st, float* part = nullptr, size_t part_cap = 0);
 hipError_t launch_time_mlp_bwd(const TimeMlpArgs& a, const float* dtemb, float* dw1, float* db1, float* dw2, float* db2, float* dnull, int B, hipStream_t st);
 
 size_t conv_packed_bytes(int mode, int taps, int Cin, int Cout);

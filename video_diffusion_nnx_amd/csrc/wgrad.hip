@@ -145,7 +145,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
     const int cbase = P.split ? sel * P.split : 0, cw = P.split ? P.split : P.Cout;
     float* const dWt = sel == 0 ? P.dW : (sel == 1 ? P.dW1 : P.dW2);
     float* const dbt = sel == 0 ? P.db : (sel == 1 ? P.db1 : P.db2);
-    if (dbt && do_bias && tid < 64 && co0 + tid < P.Cout) atomicAdd(dbt + co0 - cbase + tid, bias_acc);
+    float* const pslot = P.part ? P.part + (size_t)blockIdx.x * P.part_E : nullptr;       // deterministic mode: this chunk's slot
+    if (dbt && do_bias && tid < 64 && co0 + tid < P.Cout) {
+        if (pslot) P.part_b[(size_t)blockIdx.x * P.Cout + co0 + tid] = bias_acc;
+        else atomicAdd(dbt + co0 - cbase + tid, bias_acc);
+    }
     // ---- accumulate into dW (Flax layout [taps][Cin][Cout]) ----
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -159,7 +163,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs P) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ci = ci0 + wi * 32 + i * 16 + 4 * q + e;
-                    if (ci < Cin && co < P.Cout) atomicAdd(dWt + ((size_t)tap * Cin + ci) * cw + co - cbase, acc[t][i][j][e]);
+                    if (ci < Cin && co < P.Cout) {
+                        if (pslot) pslot[((size_t)tap * Cin + ci) * P.Cout + co] = acc[t][i][j][e];
+                        else atomicAdd(dWt + ((size_t)tap * Cin + ci) * cw + co - cbase, acc[t][i][j][e]);
+                    }
                 }
             }
     }
@@ -415,12 +422,26 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel
     const int cbase = P.split ? sel * P.split : 0, cw = P.split ? P.split : P.Cout;
     float* const dWt = sel == 0 ? P.dW : (sel == 1 ? P.dW1 : P.dW2);
     float* const dbt = sel == 0 ? P.db : (sel == 1 ? P.db1 : P.db2);
+    float* const pslot = P.part ? P.part + (size_t)blockIdx.x * P.part_E : nullptr;       // deterministic mode: this chunk's slot
     if (do_bias) {                                             // (uniform per workgroup)
         const int pc = tid & 15;
-        atomicAdd(&bsum[pc * 4 + 0], bias4.x); atomicAdd(&bsum[pc * 4 + 1], bias4.y);
-        atomicAdd(&bsum[pc * 4 + 2], bias4.z); atomicAdd(&bsum[pc * 4 + 3], bias4.w);
-        __syncthreads();
-        if (dbt && tid < 64 && co0 + tid < P.Cout) atomicAdd(dbt + co0 - cbase + tid, bsum[tid]);
+        if (pslot) {
+            // fixed-order sum of the threads that share a channel quadruple (pc): through the staging area, which nobody reads any more
+            __syncthreads();
+            float4* bred = reinterpret_cast<float4*>(As);
+            bred[tid] = bias4;
+            __syncthreads();
+            if (tid < 64 && co0 + tid < P.Cout) {
+                float t = 0.f;
+                for (int k = 0; k < 256 * NG / 16; ++k) { const float4 v = bred[k * 16 + (tid >> 2)]; t += (tid & 3) == 0 ? v.x : (tid & 3) == 1 ? v.y : (tid & 3) == 2 ? v.z : v.w; }
+                if (dbt) P.part_b[(size_t)blockIdx.x * P.Cout + co0 + tid] = t;
+            }
+        } else {
+            atomicAdd(&bsum[pc * 4 + 0], bias4.x); atomicAdd(&bsum[pc * 4 + 1], bias4.y);
+            atomicAdd(&bsum[pc * 4 + 2], bias4.z); atomicAdd(&bsum[pc * 4 + 3], bias4.w);
+            __syncthreads();
+            if (dbt && tid < 64 && co0 + tid < P.Cout) atomicAdd(dbt + co0 - cbase + tid, bsum[tid]);
+        }
     }
 #pragma unroll
     for (int tt = 0; tt < NTW; ++tt) {
@@ -434,7 +455,10 @@ __global__ __launch_bounds__(256 * NG, NG == 1 ? 5 : 1) void conv_wgrad16_kernel
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ci = ci0 + wi * 32 + i * 16 + 4 * q + e;
-                    if (ci < Cin && co < P.Cout) atomicAdd(dWt + ((size_t)tap * Cin + ci) * cw + co - cbase, acc[tt][i][j][e]);
+                    if (ci < Cin && co < P.Cout) {
+                        if (pslot) pslot[((size_t)tap * Cin + ci) * P.Cout + co] = acc[tt][i][j][e];
+                        else atomicAdd(dWt + ((size_t)tap * Cin + ci) * cw + co - cbase, acc[tt][i][j][e]);
+                    }
                 }
             }
     }
@@ -566,17 +590,31 @@ __global__ __launch_bounds__(256, NCO == 4 ? 2 : 4) void wgrad1x1_kernel(const W
         dWt = sel == 0 ? P.dW : (sel == 1 ? P.dW1 : P.dW2);
         dbt = sel == 0 ? P.db : (sel == 1 ? P.db1 : P.db2);
     };
+    float* const pslot = P.part ? P.part + (size_t)blockIdx.x * P.part_E : nullptr;       // deterministic mode: this K chunk's slot
     if (do_bias) {                                                // (uniform per workgroup)
         const int pc = tid % (16 * NCO);
-        atomicAdd(&bsum[pc * 4 + 0], bias4.x); atomicAdd(&bsum[pc * 4 + 1], bias4.y);
-        atomicAdd(&bsum[pc * 4 + 2], bias4.z); atomicAdd(&bsum[pc * 4 + 3], bias4.w);
-        __syncthreads();
-        for (int i = tid; i < 64 * NCO; i += 256) {
-            const int co = co0 + i;
-            if (co < P.Cout) {
-                float* dWt; float* dbt; int cbase, cw;
-                target(co, dWt, dbt, cbase, cw);
-                if (dbt) atomicAdd(dbt + co - cbase, bsum[i]);
+        if (pslot) {
+            __syncthreads();                                      // (the staging areas are free: fixed-order sum through them)
+            float4* bred = reinterpret_cast<float4*>(Bs);
+            bred[tid] = bias4;
+            __syncthreads();
+            for (int i = tid; i < 64 * NCO; i += 256) {
+                const int co = co0 + i;
+                float t = 0.f;
+                for (int k = 0; k < 256 / (16 * NCO); ++k) { const float4 v = bred[k * 16 * NCO + (i >> 2)]; t += (i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w; }
+                if (co < P.Cout) P.part_b[(size_t)blockIdx.x * P.Cout + co] = t;
+            }
+        } else {
+            atomicAdd(&bsum[pc * 4 + 0], bias4.x); atomicAdd(&bsum[pc * 4 + 1], bias4.y);
+            atomicAdd(&bsum[pc * 4 + 2], bias4.z); atomicAdd(&bsum[pc * 4 + 3], bias4.w);
+            __syncthreads();
+            for (int i = tid; i < 64 * NCO; i += 256) {
+                const int co = co0 + i;
+                if (co < P.Cout) {
+                    float* dWt; float* dbt; int cbase, cw;
+                    target(co, dWt, dbt, cbase, cw);
+                    if (dbt) atomicAdd(dbt + co - cbase, bsum[i]);
+                }
             }
         }
     }
@@ -593,26 +631,80 @@ __global__ __launch_bounds__(256, NCO == 4 ? 2 : 4) void wgrad1x1_kernel(const W
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int ci = ci0 + wi * 32 + i * 16 + 4 * q + e;
-                    if (ci < Cin) atomicAdd(dWt + (size_t)ci * cw + co - cbase, acc[s][i][j][e]);
+                    if (ci < Cin) {
+                        if (pslot) pslot[(size_t)ci * P.Cout + co] = acc[s][i][j][e];
+                        else atomicAdd(dWt + (size_t)ci * cw + co - cbase, acc[s][i][j][e]);
+                    }
                 }
         }
 }
 
+// deterministic mode: dst (+= the split targets) = sum over the slots, in slot order; one thread per element.  Slot k of element e is
+// part[k * slot_stride + e]
+__global__ __launch_bounds__(256) void slot_sum_kernel(const float* __restrict__ part, int nslots, size_t slot_stride, long E, int Cout, int split,
+                                                       float* __restrict__ d0, float* __restrict__ d1, float* __restrict__ d2) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < E; e += (long)gridDim.x * 256) {
+        float t = 0.f;
+        // 8 slots in flight per thread (the slots were written by other CUs a moment ago: every load is a trip to the memory side)
+        int k = 0;
+        for (; k + 8 <= nslots; k += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(k + u) * slot_stride + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += v[u];
+        }
+        for (; k < nslots; ++k) t += part[(size_t)k * slot_stride + e];
+        if (split) {
+            const long row = e / Cout; const int co = (int)(e - row * Cout), sel = co / split;
+            float* d = sel == 0 ? d0 : (sel == 1 ? d1 : d2);
+            if (d) d[row * split + co - sel * split] += t;
+        } else if (d0) d0[e] += t;
+    }
+}
+hipError_t launch_slot_sum(const float* part, int nslots, size_t slot_stride, long E, int Cout, int split, float* d0, float* d1, float* d2, hipStream_t st) {
+    const int blocks = (int)std::max<long>(1, std::min<long>((E + 255) / 256, 2048));
+    hipLaunchKernelGGL(slot_sum_kernel, dim3(blocks), dim3(256), 0, st, part, nslots, slot_stride, E, Cout, split, d0, d1, d2);
+    return hipGetLastError();
+}
+static hipError_t launch_wgrad_finalize(const float* part, int nslots, long E, int Cout, int split, float* d0, float* d1, float* d2, hipStream_t st) {
+    return launch_slot_sum(part, nslots, (size_t)E, E, Cout, split, d0, d1, d2, st);
+}
+// slots a launch needs: `chunks` dW tiles of E floats + `chunks` bias rows
+static bool wgrad_det_setup(WgradArgs& a, long chunks, long E) {
+    a.part_E = E; a.part_b = nullptr;
+    if (!a.part) return false;
+    const size_t need = (size_t)chunks * ((size_t)E + (size_t)a.Cout);
+    if (need > a.part_cap) { a.part = nullptr; return false; }
+    a.part_b = a.part + (size_t)chunks * E;
+    return true;
+}
+static hipError_t wgrad_det_finish(const WgradArgs& a, long chunks, hipStream_t st) {
+    hipError_t e = launch_wgrad_finalize(a.part, (int)chunks, a.part_E, a.Cout, a.split, a.dW, a.dW1, a.dW2, st);
+    if (e != hipSuccess || !a.db) return e;
+    return launch_wgrad_finalize(a.part_b, (int)chunks, a.Cout, a.Cout, a.split, a.db, a.db1, a.db2, st);
+}
+
 template <bool X16, bool DY16, int NCO>
-static hipError_t launch_wgrad1x1_t(const WgradArgs& a, long target_wgs, hipStream_t st) {
+static hipError_t launch_wgrad1x1_t(const WgradArgs& a0, long target_wgs, hipStream_t st) {
+    WgradArgs a = a0;
     const long rows = (long)a.NF * a.H * a.W;
     const int Cin = a.C0 + a.C1;
     const int ci_tiles = (Cin + 63) / 64, co_tiles = (a.Cout + 64 * NCO - 1) / (64 * NCO);
     const long ntiles = (rows + 63) / 64;
     const long chunks = std::max<long>(1, std::min<long>(ntiles, target_wgs / ((long)ci_tiles * co_tiles)));
     const int per = (int)((ntiles + chunks - 1) / chunks);
+    const long nslots = (ntiles + per - 1) / per;
     const size_t lds = 64 * WG_RSB + 64 * (NCO * 128 + 16) + 64 * NCO * 4;
-    hipLaunchKernelGGL((wgrad1x1_kernel<X16, DY16, NCO>), dim3((unsigned)((ntiles + per - 1) / per), ci_tiles, co_tiles), dim3(256), lds, st, a, rows, per);
-    return hipGetLastError();
+    const bool det = wgrad_det_setup(a, nslots, (long)Cin * a.Cout);
+    hipLaunchKernelGGL((wgrad1x1_kernel<X16, DY16, NCO>), dim3((unsigned)nslots, ci_tiles, co_tiles), dim3(256), lds, st, a, rows, per);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !det) return e;
+    return wgrad_det_finish(a, nslots, st);
 }
 
 // out[c] += sum over rows of x[row][c]   (bias / LayerNorm-beta gradients); x is [rows][C] fp32
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int C) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows, int C, float* __restrict__ part) {
     __shared__ float red[256];
     const int cpt = (C + 3) / 4;                              // float4 columns
     const int lanes_c = cpt < 256 ? cpt : 256;
@@ -633,7 +725,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
             if (rq == 0) {
                 float t = 0.f;
                 for (int k = 0; k < rl; ++k) t += red[k * lanes_c + cq];
-                if (cb * 4 + e < C) atomicAdd(out + cb * 4 + e, t);
+                if (cb * 4 + e < C) { if (part) part[(size_t)blockIdx.x * C + cb * 4 + e] = t; else atomicAdd(out + cb * 4 + e, t); }
             }
         }
     }
@@ -677,6 +769,8 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
     const long target_wgs9 = 256;
     long chunks = std::max<long>(1, std::min<long>(patches, (a.taps > 1 ? target_wgs9 : target_wgs) / std::max<long>(1, tiles)));
     dim3 grid((unsigned)chunks, ci_tiles, a.co_tiles * tap_groups);
+    float* const part_in = a.part;                        // (the 1x1 GEMM form below sizes its own slots)
+    const bool det = wgrad_det_setup(a, chunks, (long)a.taps * Cin * a.Cout);
     if (a.bf16_mma && (a.PW == 8 || a.PW == 16)) {
         a.pwl = a.PW == 8 ? 3 : 4;
         const size_t lds16 = ((size_t)IH * IW + (size_t)a.PH * a.sb * a.PW * a.sb) * WG_RSB + 4 * 64 * 4 + 32 * 4;
@@ -693,6 +787,7 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
         const int use_1x1 = 2;   // 0: patch kernel, 1: GEMM form for wide outputs only, 2: always
         if (use_1x1 && NT == 1 && a.kind == 0 && a.stride == 1 && !a.pro && (a.Cout % 256 == 0 || use_1x1 == 2)) {
             const long wgs4 = 512;
+            a.part = part_in;
             if (a.Cout % 256 == 0) {
                 if (a.x0_bf16) return a.dy_bf16 ? launch_wgrad1x1_t<true, true, 4>(a, wgs4, st) : launch_wgrad1x1_t<true, false, 4>(a, wgs4, st);
                 return a.dy_bf16 ? launch_wgrad1x1_t<false, true, 4>(a, wgs4, st) : launch_wgrad1x1_t<false, false, 4>(a, wgs4, st);
@@ -708,21 +803,26 @@ hipError_t launch_conv_wgrad(WgradArgs a, hipStream_t st) {
         else VDX_WG16_IO(8, 2, true);
 #undef VDX_WG16_IO
 #undef VDX_WG16
-        return hipGetLastError();
+        { hipError_t e = hipGetLastError(); if (e != hipSuccess || !det) return e; }
+        return wgrad_det_finish(a, chunks, st);
     }
 #define VDX_WG(NT_) do { auto kfn = conv_wgrad_kernel<NT_>;                                                           \
         if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); if (e != hipSuccess) return e; } \
         hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, a); } while (0)
     if (NT == 1) VDX_WG(1); else if (NT == 9) VDX_WG(9); else VDX_WG(8);
 #undef VDX_WG
-    return hipGetLastError();
+    { hipError_t e = hipGetLastError(); if (e != hipSuccess || !det) return e; }
+    return wgrad_det_finish(a, chunks, st);
 }
 
-hipError_t launch_colsum(const float* x, float* out, long rows, int C, hipStream_t st) {
+hipError_t launch_colsum(const float* x, float* out, long rows, int C, hipStream_t st, float* part, size_t part_cap) {
     const int cpt = (C + 3) / 4, lanes_c = cpt < 256 ? cpt : 256, rl = 256 / lanes_c;
     const int blocks = (int)std::max<long>(1, std::min<long>((rows + rl - 1) / rl, 1024));
-    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, st, x, out, rows, C);
-    return hipGetLastError();
+    if (part && (size_t)blocks * C > part_cap) part = nullptr;
+    hipLaunchKernelGGL(colsum_kernel, dim3(blocks), dim3(256), 0, st, x, out, rows, C, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !part) return e;
+    return launch_wgrad_finalize(part, blocks, C, C, 0, out, nullptr, nullptr, st);      // every workgroup wrote its row of column sums: add them in order
 }
 
 hipError_t launch_add_inplace(float* y, const float* x, long n, hipStream_t st) {
