@@ -325,7 +325,9 @@ typedef struct {
                                                           VDX_MODE_BF16 handle's backward uses) */
 } vdx_wgrad_desc;
 
-/* dW += Xhat^T (*) dY on exact-f32 MFMA (both arithmetic modes use it). */
+/* dW += Xhat^T (*) dY on exact-f32 MFMA (both arithmetic modes use it).  This block-level entry point has no workspace and accumulates with
+ * float atomics (the result is reproducible to rounding); inside vdx_unet_backward the same kernels store per-workgroup partial tiles
+ * into the backward workspace and a second pass adds them in a fixed order (bit-reproducible gradients, round 3). */
 int vdx_conv_backward_weights(const vdx_wgrad_desc* d, void* stream);
 
 /* Backward of act = SiLU((gamma*GroupNorm(y)+beta)*(1+s)+sh) and, when r != NULL, of out = act + LayerNorm_C(r)
@@ -380,7 +382,10 @@ int vdx_colsum(const float* x, float* out, long rows, int c, void* stream);
  * vdx_num_stages() stages (head = num_stages-1, ups, mid, downs, stem = 0) so that the caller can all-reduce finished
  * gradient buckets while earlier stages still run: call with descending, contiguous [stage_hi .. stage_lo] ranges, starting
  * at the head (which zeroes `grads`).  grads: flat fp32, same layout as params (vdx_param_info).
- * packed_t: vdx_pack_params_bwd (transposed packing for the data gradients). */
+ * packed_t: vdx_pack_params_bwd (transposed packing for the data gradients).
+ * The gradients are bit-reproducible run to run (round 3): no sum of the pass depends on the arrival order of workgroups or of the
+ * two streams it runs on (per-workgroup partial slots in bwd_workspace + a fixed-order second pass; vdx_bwd_workspace_bytes includes
+ * 2 x 48 MB for them). */
 int vdx_num_stages(const vdx_handle* h);
 size_t vdx_packed_bwd_bytes(const vdx_handle* h);
 int vdx_pack_params_bwd(const vdx_handle* h, const float* params, void* packed_t, void* stream);
