@@ -79,3 +79,22 @@ def test_device_prefetcher_pinned_side_stream():
         assert dev.is_cuda and dev.shape == (2, 1, 4, 16, 16)
         assert torch.equal(dev.cpu(), batches[i][2:4])
     assert i == 5
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16'])
+def test_train_steps_are_bit_reproducible(tmp_path, mode):
+    """Two trainers built alike take the same three steps on the same batches: losses, parameters, Adam moments and EMA end bit-identical
+    (round 3: forward statistics in f64, backward without float atomics, Philox noise keyed by (seed, step) -- a train step is a function of
+    its inputs only)."""
+    ends = []
+    for run in range(2):
+        _, unet, gd, tr = _mk(tmp_path / f'r{run}', mode=mode, steps=3)
+        g = torch.Generator().manual_seed(5)
+        losses = []
+        for step in range(3):
+            batch = torch.rand(2, 1, 4, 8, 8, generator=g)
+            losses.append(tr.train_step(batch, step=step).item())
+        torch.cuda.synchronize()
+        ends.append((losses, unet.flat_params.clone(), tr.ema.clone()))
+    assert ends[0][0] == ends[1][0], (ends[0][0], ends[1][0])
+    assert torch.equal(ends[0][1], ends[1][1]) and torch.equal(ends[0][2], ends[1][2])

@@ -37,6 +37,9 @@ __device__ __forceinline__ void nb_build_tables(const NormBwdArgs& P, int b, flo
     __syncthreads();
 }
 
+#ifndef VDX_NB_U
+#define VDX_NB_U 4            // pixels per lane group and pass of the reduce kernel (VPL = 1; half of it for wider rows)
+#endif
 template <int VPL>
 __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs P) {
     __shared__ float mu[1024], rsd[1024], ta[1024], td[1024];
@@ -52,7 +55,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs P) {
     for (int v = 0; v < VPL; ++v) { r0[v] = r1[v] = g0[v] = g1[v] = make_float4(0.f, 0.f, 0.f, 0.f); }
     // U pixels per lane group and pass: every load of the pass (r, y, dact of U pixels) is issued before the first use, so a wave
     // has 3 * U * VPL 16-byte loads in flight (the launch has < 1 wave per SIMD: nothing else hides the latency)
-    constexpr int U = VPL == 1 ? 4 : 2;
+    constexpr int U = VPL == 1 ? VDX_NB_U : VDX_NB_U / 2;
     const long pstride = (long)gridDim.x * ppb;
     for (long pix0 = (long)blockIdx.x * ppb + pl; pix0 < P.pix_per_sample; pix0 += pstride * U) {
         float4 rr[U][VPL], yv4[U][VPL], da4[U][VPL];
@@ -330,7 +333,7 @@ static int norm_bwd_reduce_wgs(int C, long pix_per_sample) {
     const int quads = C / 4;
     int lpp = 1;
     while (lpp < quads && lpp < 64) lpp <<= 1;
-    const int vpl = (quads + lpp - 1) / lpp, ppb = 256 / lpp, U = vpl == 1 ? 4 : 2;
+    const int vpl = (quads + lpp - 1) / lpp, ppb = 256 / lpp, U = vpl == 1 ? VDX_NB_U : VDX_NB_U / 2;
     return (int)std::max<long>(1, std::min<long>(256, (pix_per_sample + (long)ppb * U * 2 - 1) / ((long)ppb * U * 2)));
 }
 
