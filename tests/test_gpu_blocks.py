@@ -40,7 +40,8 @@ def test_resblock_tail(C, B, shape):
 
 
 @pytest.mark.parametrize('c0,c1,C,B,shape', [(64, 64, 64, 2, (4, 16, 16)), (64, 0, 128, 1, (3, 8, 8)), (128, 128, 64, 2, (2, 8, 8)),
-                                             (128, 0, 256, 1, (5, 4, 4)), (256, 0, 64, 1, (4, 32, 32)), (64, 64, 64, 3, (16, 64, 64))])
+                                             (128, 0, 256, 1, (5, 4, 4)), (256, 0, 64, 1, (4, 32, 32)), (64, 64, 64, 3, (16, 64, 64)),
+                                             (32, 32, 32, 2, (10, 16, 16)), (32, 0, 64, 1, (10, 8, 8)), (64, 64, 32, 1, (3, 8, 8))])   # dim-32 networks (config_v2_2 as written)
 def test_resblock_tail_with_res_conv_bf16(c0, c1, C, B, shape):
     """resblock_tail_rc16_kernel (bf16 activation storage): the block's 1x1 res_conv computed inside the tail from the (concat) block
     input.  Reference = the oracle ops in fp64 on the SAME bf16-rounded tensors and bf16-rounded res_conv weights; the kernel

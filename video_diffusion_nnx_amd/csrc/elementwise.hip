@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256, (CIN == 128 && COUT == 64) ? 4 : (COUT <= 128 
         const int tm = row >> 4, rr = row & 15;
         const int co = (tm >> 1) * 32 + (rr >> 2) * 8 + (tm & 1) * 4 + (rr & 3);
         *reinterpret_cast<uint4*>(Wl + row * WRS + c * 16) =
-            *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.rc_w) + ((size_t)co * CIN + c * 8) * 2);
+            *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.rc_w) + ((size_t)co * ((CIN + 63) / 64 * 64) + c * 8) * 2);      // (packed rows are padded to 64 input channels)
     }
     gn_mean_rstd_wg(P.stats, b, P.groups, (double)P.pix_per_sample * (COUT / P.groups), gm, tid, 256);
     __syncthreads();
@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256, (CIN == 128 && COUT == 64) ? 4 : (COUT <= 128 
 }
 
 bool tail_rc16_supported(int cin, int c0, int cout, long pix_per_sample) {
-    const bool shape = (cin == 128 && cout == 64) || (cin == 64 && cout == 128) || (cin == 256 && cout == 64) || (cin == 128 && cout == 256);
+    const bool shape = (cin == 128 && cout == 64) || (cin == 64 && cout == 128) || (cin == 256 && cout == 64) || (cin == 128 && cout == 256) ||
+                       (cin == 64 && cout == 32) || (cin == 32 && cout == 64) || (cin == 128 && cout == 32);      // (dim-32 networks: the YAML-literal config_v2_2)
     return shape && (c0 == cin || 2 * c0 == cin) && pix_per_sample % 16 == 0 && pix_per_sample * std::max(cin, cout) * 2 < (1L << 31);
 }
 
@@ -303,6 +304,9 @@ hipError_t launch_resblock_tail(TailArgs a, hipStream_t st) {
         if (cin == 128 && a.C == 64) return launch_tail_rc16<128, 64>(a, st);
         if (cin == 64 && a.C == 128) return launch_tail_rc16<64, 128>(a, st);
         if (cin == 256 && a.C == 64) return launch_tail_rc16<256, 64>(a, st);
+        if (cin == 64 && a.C == 32) return launch_tail_rc16<64, 32>(a, st);
+        if (cin == 32 && a.C == 64) return launch_tail_rc16<32, 64>(a, st);
+        if (cin == 128 && a.C == 32) return launch_tail_rc16<128, 32>(a, st);
         return launch_tail_rc16<128, 256>(a, st);
     }
     if (a.y2_bf16 && a.r_bf16 && a.out_bf16 && a.C % 8 == 0) {

@@ -79,6 +79,8 @@ def resblock_tail_rc_bf16(y2, x0, x1, rc_kernel, rc_bias, stats, gn_gamma, gn_be
     pix = y2.numel() // (B * C)
     c0, c1 = x0.shape[-1], (0 if x1 is None else x1.shape[-1])
     wp = rc_kernel.t().contiguous().to(torch.bfloat16)           # [C][Cin], K-contiguous: the packed operand layout
+    if (c0 + c1) % 64:                                           # (rows padded to 64 input channels, as vdx_pack_conv_weights lays them out)
+        wp = torch.nn.functional.pad(wp, (0, 64 - (c0 + c1) % 64)).contiguous()
     out = torch.empty_like(y2)
     L.check(L.vdx_resblock_tail_rc_bf16(L.ptr(y2), L.ptr(x0), None if x1 is None else L.ptr(x1), c0, c1, L.ptr(wp), L.ptr(rc_bias),
                                         L.ptr(out), L.ptr(stats), L.ptr(gn_gamma), L.ptr(gn_beta), groups, L.ptr(ln_gamma),
