@@ -949,15 +949,7 @@ static hipError_t launch_conv64d(const ConvArgs& a, hipStream_t st) {
 #ifndef VDX_C64R_DIAG
 #define VDX_C64R_DIAG 0            // timing knock-outs (wrong results): 1 = no MFMAs, 2 = no fragment reads
 #endif
-// PRO (GroupNorm-apply . (scale + 1) + shift -> SiLU on the input, modules.py:173-179): the third buffer buys the prologue a whole tile
-// period -- while the MFMAs of tile t run, every lane transforms IN PLACE the pieces of tile t + 1 that its own LDS-DMA instructions
-// brought (issued a period earlier: a counted vmcnt, no barrier between landing and transform), one piece between two MFMA steps, the
-// two waves of a SIMD on alternating steps; tile t + 2 is in flight meanwhile.  conv64p_kernel (weights + two tiles in LDS, next tile
-// through registers) measured 417-440 us at level 0 against 270 for the plain form here.
-#ifndef VDX_C64R_PSTEP
-#define VDX_C64R_PSTEP 2           // one piece every PSTEP MFMA steps (12 steps, <= 6 pieces per lane and tile)
-#endif
-template <bool PRO, bool OUT16>
+template <bool OUT16>
 __global__ __launch_bounds__(512) void conv64r_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
     using M = Mma<MODE_BF16>;
     constexpr int NDMA = 41, NK = (NDMA + 7) / 8;
@@ -965,9 +957,6 @@ __global__ __launch_bounds__(512) void conv64r_kernel(const ConvArgs P, const in
     char* Al = smem;                                  // [3][328 rows][128 B]
     double* chs = reinterpret_cast<double*>(Al + 3 * C64D_APL);   // [2][64] channel sum / sumsq of the current sample (f64: order-independent)
     float* biasl = reinterpret_cast<float*>(chs + 128);           // [64]
-    float* coefA = biasl + 64;                                    // PRO: [64] x -> silu(x * coefA + coefD)
-    float* coefD = coefA + 64;
-    float* gmean = coefD + 64;                                    // [32][mean, rstd]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1045,51 +1034,6 @@ __global__ __launch_bounds__(512) void conv64r_kernel(const ConvArgs P, const in
         __syncthreads();
     };
 
-    // GroupNorm-apply coefficients of sample b (all threads call; ends with a barrier)
-    auto make_coef = [&](int b) {
-        if constexpr (!PRO) return;
-        gn_mean_rstd_wg(P.in_stats, b, P.groups, (double)P.F * P.H * P.W * (64 / P.groups), gmean, tid, 512);
-        __syncthreads();
-        int tt = tid;
-        asm volatile("" : "+v"(tt));
-        if (tt < 64) {
-            const int g = tt / (64 / P.groups);
-            const float m = gmean[2 * g], rsd = gmean[2 * g + 1];
-            float sc = 1.f, sh = 0.f;
-            if (P.ss) { sc = P.ss[(size_t)b * P.ss_stride + tt] + 1.f; sh = P.ss[(size_t)b * P.ss_stride + 64 + tt]; }
-            coefA[tt] = rsd * P.gamma[tt] * sc;
-            coefD[tt] = (P.beta[tt] - m * rsd * P.gamma[tt]) * sc + sh;
-        }
-        __syncthreads();
-    };
-    // prologue of piece k of tile t (in buffer `buf`), in place: the 16 bytes this lane's k-th DMA instruction of the tile wrote.
-    // Out-of-image pieces came from the zero page and stay zero (the padding is applied AFTER the activation).
-    auto transform = [&](int t, int buf, int k) __attribute__((always_inline)) {
-        if (wave_u + 8 * k >= NDMA) return;            // (uniform)
-        int f, ty, tx; decode(t, f, ty, tx);
-        int ln = lane;
-        asm volatile("" : "+v"(ln));
-        const int hp = (wave_u + 8 * k) * 8 + (ln >> 3);
-        const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;
-        const int gy = ty * 16 - 1 + hy, gx = tx * 16 - 1 + hx;
-        const bool ok = hp < C64_HALO && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
-        const int c0 = ((ln & 7) ^ (hx & 7)) << 3;     // first of the piece's 8 channels
-        char* pp = Al + buf * C64D_APL + (wave_u + 8 * k) * 1024 + ln * 16;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(pp);
-        const float4 a0 = *reinterpret_cast<const float4*>(coefA + c0), a1 = *reinterpret_cast<const float4*>(coefA + c0 + 4);
-        const float4 d0 = *reinterpret_cast<const float4*>(coefD + c0), d1 = *reinterpret_cast<const float4*>(coefD + c0 + 4);
-        const float ca[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, cd[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
-        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-        unsigned o4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float lo = silu_f(fmaf(__uint_as_float(w4[j] << 16), ca[2 * j], cd[2 * j]));
-            const float hi = silu_f(fmaf(__uint_as_float(w4[j] & 0xFFFF0000u), ca[2 * j + 1], cd[2 * j + 1]));
-            o4[j] = ok ? pack_bf16x2(lo, hi) : 0u;
-        }
-        *reinterpret_cast<u32x4*>(pp) = u32x4{o4[0], o4[1], o4[2], o4[3]};
-    };
-
     // fragment addressing (see the header): B fragment of (tn, dy, dx, ch) = At + rowbase + bdx[dx][ch] + (tn + dy) * 18 * 128
     int bdx[3][2];
 #pragma unroll
@@ -1104,12 +1048,6 @@ __global__ __launch_bounds__(512) void conv64r_kernel(const ConvArgs P, const in
     __syncthreads();                                  // chs + bias visible
     dma(t0, 0);
     if (t0 + 1 < t1) { dma(t0 + 1, 1); wait_vm<5>(); } else wait_vm<0>();      // tile t0 has landed (a wave issues 5 or 6 instructions per tile)
-    int bcoef = bcur;                                 // PRO: sample the coefficients in LDS belong to
-    if constexpr (PRO) {
-        make_coef(bcur);
-#pragma unroll
-        for (int k = 0; k < NK; ++k) transform(t0, 0, k);
-    }
     __syncthreads();
     int buf = 0;
     for (int t = t0; t < t1; ++t) {
@@ -1117,18 +1055,6 @@ __global__ __launch_bounds__(512) void conv64r_kernel(const ConvArgs P, const in
         int fn = fcur, tyn = tyc, txn = txc, bn = bcur;
         if (more) { decode(t + 1, fn, tyn, txn); bn = fn / P.F; }
         if (more2) dma(t + 2, buf >= 1 ? buf - 1 : 2);    // (buf + 2) % 3: the buffer of tile t - 1, last read before the previous barrier
-        const int bufn = buf == 2 ? 0 : buf + 1;
-        if constexpr (PRO) {
-            // this lane's pieces of tile t + 1 have landed: its DMA instructions are older than the previous iteration's row stores (none
-            // before the first iteration) and the 5 or 6 instructions just issued for tile t + 2 -- the stores may stay in flight
-            constexpr int NSTP = OUT16 ? 4 : 8;
-            if (more) {
-                if (t == t0) { if (more2) wait_vm<5>(); else wait_vm<0>(); }
-                else if (!more2) wait_vm<NSTP>();
-                else if (wave_u == 0) wait_vm<NSTP + 6>();
-                else wait_vm<NSTP + 5>();
-            }
-        }
         const char* At = Al + buf * C64D_APL + rowbase;
         const int oy0 = tyc * 16 + 4 * wp, ox = txc * 16 + lp;
         // Sliding window over the wave's 6 halo rows: a fragment of halo row hr serves output rows hr, hr - 1, hr - 2 (taps dy = 0, 1, 2: all
@@ -1165,10 +1091,6 @@ __global__ __launch_bounds__(512) void conv64r_kernel(const ConvArgs P, const in
                         }
                     }
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (PRO) {                   // one piece of tile t + 1 between two MFMA steps; the waves of a SIMD (w, w + 4) on alternating steps
-                    const int so = s_ - (wave_u >= 4 ? 1 : 0);
-                    if (more && so >= 0 && so % VDX_C64R_PSTEP == 0 && so / VDX_C64R_PSTEP < NK) transform(t + 1, bufn, so / VDX_C64R_PSTEP);
-                }
             }
             if (hr >= 2) {
                 const int tn = hr - 2;
@@ -1194,16 +1116,11 @@ __global__ __launch_bounds__(512) void conv64r_kernel(const ConvArgs P, const in
         }
         // tile t + 1 has landed: everything older than this iteration's DMA (5 or 6 instructions, when issued) and its 4 or 8 stores
         constexpr int NST = OUT16 ? 4 : 8;
-        if constexpr (!PRO) { if (more2) wait_vm<5 + NST>(); else wait_vm<NST>(); }
+        if (more2) wait_vm<5 + NST>(); else wait_vm<NST>();
         if (more && bn != bcur) { flush_stats(bcur); bcur = bn; }    // uniform: the next tile belongs to another sample
-        if constexpr (PRO) {
-            // coefficients of the sample tile t + 2 belongs to, before its transform starts (every transform of this iteration is behind the
-            // barrier make_coef begins with)
-            if (more2) { int f2, ty2, tx2; decode(t + 2, f2, ty2, tx2); const int b2 = f2 / P.F; if (b2 != bcoef) { make_coef(b2); bcoef = b2; } }
-        }
         fcur = fn; tyc = tyn; txc = txn;
-        buf = bufn;
-        __syncthreads();                              // tile t + 1 landed (PRO: transformed) everywhere; everybody is done reading tile t
+        buf = buf == 2 ? 0 : buf + 1;
+        __syncthreads();                              // tile t + 1 landed everywhere; everybody is done reading tile t
     }
     flush_stats(bcur);
 }
@@ -1215,16 +1132,15 @@ static hipError_t launch_conv64r(const ConvArgs& a, hipStream_t st) {
     const int grid = std::min(total, cus);
     const int tpb = (total + grid - 1) / grid;
     const int nblocks = (total + tpb - 1) / tpb;
-    const size_t lds = 3 * (size_t)C64D_APL + 128 * 8 + 64 * 4 + (64 + 64 + 64) * 4;
+    const size_t lds = 3 * (size_t)C64D_APL + 128 * 8 + 64 * 4;
     auto launch = [&](auto kfn) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kfn, dim3(nblocks), dim3(512), lds, st, a, tpb, total);
         return hipGetLastError();
     };
-    if (!a.x0_bf16 || a.res) return hipErrorInvalidValue;
-    if (a.pro) return a.y_bf16 ? launch(conv64r_kernel<true, true>) : launch(conv64r_kernel<true, false>);
-    return a.y_bf16 ? launch(conv64r_kernel<false, true>) : launch(conv64r_kernel<false, false>);
+    if (a.pro || !a.x0_bf16 || a.res) return hipErrorInvalidValue;
+    return a.y_bf16 ? launch(conv64r_kernel<true>) : launch(conv64r_kernel<false>);
 }
 
 // ---- "conv64q": the weights-in-registers scheme with 16 output channels x 128 pixels per wave ------------------------------------------
@@ -1991,9 +1907,6 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
 #ifndef VDX_C64R
 #define VDX_C64R 1
 #endif
-#ifndef VDX_C64R_PRO
-#define VDX_C64R_PRO 0       // the prologue form of conv64r_kernel measured SLOWER than conv64p_kernel (449 vs 422 us at level 0, r03): built, tested, not dispatched
-#endif
 #ifndef VDX_C64Q
 #define VDX_C64Q 5             // conv64q_kernel (16 channels x 128 pixels per wave) for: 1 = the prologue form, 2 = the plain form, 4 = 128 input channels
 #endif
@@ -2002,9 +1915,10 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
                 LaunchScope ls(st, "conv64q_kernel", cw.flops, cw.bytes, "<cin 64, pro %d, y16 %d> %s", a.pro, a.y_bf16, cw.shape);
                 return launch_conv64q(a, st);
             }
-            if (VDX_C64R && a.x0_bf16 && !a.res && !VDX_C64_NODMA && (!a.pro || VDX_C64R_PRO)) {      // weights in registers, three-deep tile ring (conv64r_kernel)
+            if (VDX_C64R && a.x0_bf16 && !a.pro && !a.res && !VDX_C64_NODMA) {      // weights in registers, three-deep tile ring (conv64r_kernel; its prologue form -- in-place transform with
+                                                                                       // the coefficients re-read per piece, 256 registers + scratch -- measured 449 us against conv64p_kernel's 422 and was removed)
                 const ConvWork cw = conv_work(mode, a);
-                LaunchScope ls(st, "conv64r_kernel", cw.flops, cw.bytes, "<pro %d, y16 %d> %s", a.pro, a.y_bf16, cw.shape);
+                LaunchScope ls(st, "conv64r_kernel", cw.flops, cw.bytes, "<pro 0, y16 %d> %s", a.y_bf16, cw.shape);
                 return launch_conv64r(a, st);
             }
             const ConvWork cw = conv_work(mode, a);
