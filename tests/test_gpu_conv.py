@@ -177,6 +177,32 @@ def test_persistent_c128_to_64_conv(concat):
     np.testing.assert_allclose(s[..., 1], (yg * yg).sum(dim=(1, 3)), rtol=2e-3)
 
 
+@pytest.mark.parametrize('c,B,Fr,S', [(32, 2, 32, 64), (64, 16, 16, 32)])
+def test_persistent_concat_conv_32_outputs(c, B, Fr, S):
+    """conv64q_kernel<64 | 128, ..., COUT 32>: the 3x3 convs on a concat input (c + c channels) with 32 output channels of dim-32 networks
+    (configs/config_v2_2.yaml as written: ups.3 block1 at 64 x 64, ups.2 block1 at 32 x 32), bf16 tensors, >= 1024 tiles; statistics of
+    samples of different scale."""
+    from video_diffusion_nnx_amd import ops
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(17 + c)
+    xa = torch.randn(B, Fr, S, S, c, generator=g)
+    xb = torch.randn(B, Fr, S, S, c, generator=g)
+    xb[1] *= 0.5
+    kern = torch.randn(1, 3, 3, 2 * c, 32, generator=g) / (9 * 2 * c) ** 0.5
+    bias = torch.randn(32, generator=g)
+    pw = ops.pack_conv_weights(kern.to(dev), 'bf16')
+    stats = ops.gn_stats_zeros(B, 8, dev)
+    y = ops.conv_forward(xa.to(dev).to(torch.bfloat16), pw, 32, mode='bf16', bias=bias.to(dev), x1=xb.to(dev).to(torch.bfloat16),
+                         out_stats=stats, y_bf16=True)
+    torch.cuda.synchronize()
+    ref = R.conv_1kk(_bf16r(torch.cat((xa, xb), -1)).double(), _bf16r(kern).double(), bias.double())
+    assert _rel(y.float().cpu().double(), ref) < 4e-3
+    s = ops.gn_stats_reduce(stats, B, 8).cpu()
+    yg = ref.reshape(B, -1, 8, 4)
+    np.testing.assert_allclose(s[..., 0], yg.sum(dim=(1, 3)), rtol=2e-3, atol=5.0)
+    np.testing.assert_allclose(s[..., 1], (yg * yg).sum(dim=(1, 3)), rtol=2e-3)
+
+
 WS_CASES = [
     # B, F, S, C0, C1, Cout            (3x3, stride 1, bf16 tensors, Cout % 128 == 0, >= 128 work items)
     (2, 16, 32, 128, 0, 128),          # level-1 shape: 16 x 16 tiles of a 32 x 32 frame, one output-channel tile

@@ -1157,13 +1157,17 @@ static hipError_t launch_conv64r(const ConvArgs& a, hipStream_t st) {
 #ifndef VDX_C64Q_VPM
 #define VDX_C64Q_VPM 6        // VALU instructions of the prologue behind each MFMA of a transform step
 #endif
-template <int CIN, bool PRO, bool OUT16>
+// COUT = 64, or 32 (level 0 / 1 of dim-32 networks: wave (wc, wp) = channels 16 wc.., pixel rows 4 wp..4 wp + 3, 6 halo rows, 12 steps); the 64 input
+// channels of the COUT = 32 form are the two 32-channel tensors of a concat input (P.C1 == 32) or one 64-channel tensor
+template <int CIN, bool PRO, bool OUT16, int COUT = 64>
 __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const int tiles_per_block, const int total_tiles) {
     using M = Mma<MODE_BF16>;
     static_assert(CIN == 64 || (CIN == 128 && !PRO), "prologue form: 64 input channels");
+    static_assert(COUT == 64 || (COUT == 32 && !PRO), "COUT");
+    constexpr int NWC = COUT / 16, NWP = 8 / NWC, RW = 16 / NWP, NHR = RW + 2, NSTEP = 2 * NHR;   // channel quarters, pixel parts, rows per wave, halo rows, steps per pass
     constexpr int NPL = CIN / 64;                     // 64-channel planes per tile
     constexpr int NDMA = 41, NK = (NDMA + 7) / 8;
-    constexpr int NST = OUT16 ? 4 : 8;                // row stores of a wave per tile
+    constexpr int NST = (OUT16 ? 1 : 2) * (RW / 2);   // row stores of a wave per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Al = smem;                                  // [3][328 rows][128 B]
     double* chs = reinterpret_cast<double*>(Al + 3 * C64D_APL);   // [2][64] channel sum / sumsq of the current sample (f64: order-independent)
@@ -1174,7 +1178,7 @@ __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const in
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc = wave_u & 3, wp = wave_u >> 2;      // output-channel quarter, pixel half (rows 8 wp .. 8 wp + 7)
+    const int wc = wave_u % NWC, wp = wave_u / NWC;   // output-channel quarter, pixel part (rows RW wp .. RW wp + RW - 1)
     const int lp = lane & 15, q = lane >> 4;
     const int tiles_x = P.W >> 4, tiles_pf = tiles_x * (P.H >> 4);
     const int t0 = blockIdx.x * tiles_per_block, t1 = min(t0 + tiles_per_block, total_tiles);
@@ -1189,12 +1193,14 @@ __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const in
             wf[tap][c] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wp) +
                 ((size_t)tap * P.wrows + P.wrow0 + wc * 16 + lp) * (CIN * 2) + c * 64 + q * 16);
     if (tid < 128) chs[tid] = 0.0;
-    if (tid < 64) biasl[tid] = P.bias ? P.bias[tid] : 0.f;
+    if (tid < 64) biasl[tid] = (P.bias && tid < COUT) ? P.bias[tid] : 0.f;
 
     const char* const zero_page = reinterpret_cast<const char*>(g_zero_page_c64d);
     const char* const xb0 = reinterpret_cast<const char*>(P.x0);
     const char* const xb1 = (CIN == 128) ? (P.C1 ? reinterpret_cast<const char*>(P.x1) : xb0 + 128) : xb0;   // plane 1: second tensor, or channels 64..127
     const int rowb = (CIN == 128 && !P.C1) ? 256 : 128;          // bytes per pixel of a plane's tensor
+    const bool split32 = CIN == 64 && P.C1 == 32;                // the plane = two 32-channel tensors (64-byte pixels): chunks 0..3 from x0, 4..7 from x1
+    const char* const xs1 = split32 ? reinterpret_cast<const char*>(P.x1) : nullptr;
     const unsigned al_base = lds_addr(Al);
     auto decode = [&](int t, int& f, int& ty, int& tx) { f = t / tiles_pf; const int r = t - f * tiles_pf; ty = r / tiles_x; tx = r - ty * tiles_x; };
     // plane pass j = t * NPL + plane lives in ring buffer j % 3
@@ -1211,11 +1217,13 @@ __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const in
             const int hy = (hp * 3641) >> 16, hx = hp - hy * 18;          // hp / 18, hp % 18 for hp < 328
             const int gy = ty * 16 - 1 + hy, gx = tx * 16 - 1 + hx;
             const bool ok = hp < C64_HALO && gy >= 0 && gy < P.H && gx >= 0 && gx < P.W;
-            const size_t off = (size_t)((f * P.H + gy) * P.W + gx) * rowb + (((ln & 7) ^ (hx & 7)) << 4);
-            glds16(ok ? static_cast<const void*>(xb + off) : static_cast<const void*>(zero_page), dst + k * 8 * 1024);
+            const int cch = (ln & 7) ^ (hx & 7);
+            const size_t pixi = (size_t)((f * P.H + gy) * P.W + gx);
+            const char* src = split32 ? (cch < 4 ? xb0 : xs1) + pixi * 64 + ((cch & 3) << 4) : xb + pixi * rowb + (cch << 4);
+            glds16(ok ? static_cast<const void*>(src) : static_cast<const void*>(zero_page), dst + k * 8 * 1024);
         }
     };
-    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, (unsigned)P.NF * P.H * P.W * 64u * (OUT16 ? 2u : 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(P.y, 0, (unsigned)P.NF * P.H * P.W * (unsigned)COUT * (OUT16 ? 2u : 4u), 0x00020000);
     // statistics of this lane's 8 channels 16 wc + 8 (q >> 1) + i (rows of both parities)
     float ssum[8], ssq[8];
 #pragma unroll
@@ -1230,7 +1238,7 @@ __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const in
             ssum[i] = 0.f; ssq[i] = 0.f;
         }
         __syncthreads();
-        const int cpg = 64 / P.out_groups;
+        const int cpg = COUT / P.out_groups;
         int tt = tid;
         asm volatile("" : "+v"(tt));
         if (tt < 2 * P.out_groups) {
@@ -1297,7 +1305,7 @@ __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const in
     for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) { const int hx = lp + dx; bdx[dx][ch] = hx * 128 + 16 * ((q + 4 * ch) ^ (hx & 7)); }
-    const int rowbase = (8 * wp) * 18 * 128;          // (wave-uniform)
+    const int rowbase = (RW * wp) * 18 * 128;         // (wave-uniform)
 
     int fcur, tyc, txc;
     decode(t0, fcur, tyc, txc);
@@ -1322,12 +1330,12 @@ __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const in
     }
     __syncthreads();
     int buf = 0, j = 0;                               // ring buffer and index of the current pass
-    f32x4 acc[8];
+    f32x4 acc[RW];
     for (int t = t0; t < t1; ++t) {
         const bool more = t + 1 < t1;
         int fn = fcur, tyn = tyc, txn = txc, bn = bcur;
         if (more) { decode(t + 1, fn, tyn, txn); bn = fn / P.F; }
-        const int oy0 = tyc * 16 + 8 * wp, ox = txc * 16 + lp;
+        const int oy0 = tyc * 16 + RW * wp, ox = txc * 16 + lp;
 #pragma unroll
         for (int plane = 0; plane < NPL; ++plane, ++j) {
             if (j + 2 < npass) {                      // (buf + 2) % 3: the buffer of pass j - 1, last read before the previous barrier
@@ -1363,19 +1371,19 @@ __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const in
                 if constexpr (XF) { pv = *reinterpret_cast<const u32x4*>(An + piece_off(0)); pok = piece_ok(0, tyn, txn); }
                 frag_read(bf[0], 0, 0);
 #pragma unroll
-                for (int hr = 0; hr < 10; ++hr) {
-                    if (plane == 0 && hr < 8) acc[hr] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int hr = 0; hr < NHR; ++hr) {
+                    if (plane == 0 && hr < RW) acc[hr] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int ch = 0; ch < 2; ++ch) {
                         const int s_ = 2 * hr + ch;
-                        if (s_ + 1 < 20) frag_read(bf[(s_ + 1) & 1], (s_ + 1) >> 1, (s_ + 1) & 1);
+                        if (s_ + 1 < NSTEP) frag_read(bf[(s_ + 1) & 1], (s_ + 1) >> 1, (s_ + 1) & 1);
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
                             for (int dy = 0; dy < 3; ++dy) {
                                 const int tn = hr - dy;
-                                if (tn < 0 || tn > 7) continue;
+                                if (tn < 0 || tn > RW - 1) continue;
                                 M::mma(acc[tn], wf[dy * 3 + dx][plane * 2 + ch], bf[s_ & 1][dx]);
                             }
                         if constexpr (XF) {
@@ -1417,7 +1425,7 @@ __global__ __launch_bounds__(512) void conv64q_kernel(const ConvArgs P, const in
                         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
 #pragma unroll
                         for (int i = 0; i < 8; ++i) { ssum[i] += v[i]; ssq[i] += v[i] * v[i]; }
-                        const unsigned gout = (unsigned)(((fcur * P.H + oy0 + ta + (q & 1)) * P.W + ox) * 64 + wc * 16 + 8 * (q >> 1));
+                        const unsigned gout = (unsigned)(((fcur * P.H + oy0 + ta + (q & 1)) * P.W + ox) * COUT + wc * 16 + 8 * (q >> 1));
                         if constexpr (OUT16)
                             __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rsy, gout * 2u, 0, 0);
                         else {
@@ -1466,6 +1474,10 @@ static hipError_t launch_conv64q(const ConvArgs& a, hipStream_t st) {
         return hipGetLastError();
     };
     if (!a.x0_bf16 || a.res || (a.C1 && !a.x1_bf16)) return hipErrorInvalidValue;
+    if (a.Cout == 32) {                               // dim-32 networks: 64 (= 32 + 32 or 64) or 128 (= 64 + 64) input channels, bf16 output
+        if (a.pro || !a.y_bf16) return hipErrorInvalidValue;
+        return a.C0 + a.C1 == 128 ? launch(conv64q_kernel<128, false, true, 32>) : launch(conv64q_kernel<64, false, true, 32>);
+    }
     if (a.C0 + a.C1 == 128) {
         if (a.pro) return hipErrorInvalidValue;
         return a.y_bf16 ? launch(conv64q_kernel<128, false, true>) : launch(conv64q_kernel<128, false, false>);
@@ -1908,7 +1920,7 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
 #define VDX_C64R 1
 #endif
 #ifndef VDX_C64Q
-#define VDX_C64Q 5             // conv64q_kernel (16 channels x 128 pixels per wave) for: 1 = the prologue form, 2 = the plain form, 4 = 128 input channels
+#define VDX_C64Q 13            // conv64q_kernel (16 channels x 128 pixels per wave) for: 1 = the prologue form, 2 = the plain form, 4 = 128 input channels, 8 = 32 output channels
 #endif
             if (a.x0_bf16 && !a.res && !VDX_C64_NODMA && (VDX_C64Q & (a.pro ? 1 : 2))) {
                 const ConvWork cw = conv_work(mode, a);
@@ -1934,6 +1946,15 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
             return launch_conv64p(a, st);
         }
         const bool in16c = a.x0_bf16 && (!a.C1 || a.x1_bf16);
+        // dim-32 networks (the YAML-literal config_v2_2): the 3x3 convs on a concat input with 32 output channels (64 = 32 + 32 -> 32 at level 0,
+        // 128 = 64 + 64 -> 32 at level 1) ran on the generic kernel (278 / 117 us at B = 64)
+        if ((VDX_C64Q & 8) && use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.Cout == 32 && in16c && !a.pro && a.y_bf16 &&
+            ((a.C0 == 32 && a.C1 == 32) || (a.C0 == 64 && a.C1 == 64)) && a.CinPad == a.C0 + a.C1 && a.wrows == 32 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 &&
+            tiles >= 1024 && (!a.out_stats || (a.out_groups <= 32 && 32 % a.out_groups == 0 && (32 / a.out_groups) <= 8 && 8 % (32 / a.out_groups) == 0))) {
+            const ConvWork cw = conv_work(mode, a);
+            LaunchScope ls(st, "conv64q_kernel", cw.flops, cw.bytes, "<cin %d, pro 0, y16 1, cout 32> %s", a.C0 + a.C1, cw.shape);
+            return launch_conv64q(a, st);
+        }
         if (use64p && mode == MODE_BF16 && a.kind == 0 && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.Cout == 64 && in16c && !a.pro &&
             ((a.C0 == 64 && a.C1 == 64) || (a.C0 == 128 && a.C1 == 0)) && a.wrows == 64 && a.wrow0 == 0 && !a.res && a.H % 16 == 0 && a.W % 16 == 0 &&
             tiles >= 1024 && (!a.out_stats || (a.out_groups <= 32 && 32 % (64 / a.out_groups) == 0 && 64 % a.out_groups == 0))) {
