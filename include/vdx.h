@@ -165,6 +165,12 @@ size_t vdx_sla_workspace_bytes(int mode, int nframes, int npix, int heads);
 int vdx_sla_forward(int mode, const float* x, float* y, const void* wq_packed, const void* wk_packed, const void* wv_packed,
                     const void* wo_packed, void* workspace, int batch, int frames, int h, int w, int c, int heads, void* stream);
 
+/* The same block on bf16 channel-last tensors (bf16 activation storage; VDX_MODE_BF16 operands).  c = 64 with >= 128 frames runs the
+ * second half on sla_out_w_kernel (one wave per 64 pixels), other shapes the kernels of vdx_sla_forward.  workspace:
+ * vdx_sla_workspace_bytes(VDX_MODE_BF16, batch*frames, h*w, heads). */
+int vdx_sla_forward_bf16(const void* x_bf16, void* y_bf16, const void* wq_packed, const void* wk_packed, const void* wv_packed,
+                         const void* wo_packed, void* workspace, int batch, int frames, int h, int w, int c, int heads, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Network-level entry points.
  * ---------------------------------------------------------------------------------------------- */

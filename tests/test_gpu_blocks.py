@@ -262,6 +262,43 @@ SLA_CASES = [
 ]
 
 
+# The SLA block on bf16 tensors (vdx_sla_forward_bf16).  C = 64 with >= 128 frames: the second half on sla_out_w_kernel (one wave per 64
+# pixels): 4 groups per frame (half of the waves idle), 16 and 64 groups per frame, 130 frames over 128+ workgroups (ragged frame ranges);
+# fewer frames / other widths keep sla_out8_kernel covered at block level.  Stated tolerance as for the attention block on bf16 tensors.
+SLA16_CASES = [
+    # B, F, H, W, C
+    (8, 16, 16, 16, 64),
+    (13, 10, 32, 32, 64),
+    (8, 16, 64, 64, 64),
+    (40, 16, 8, 8, 64),        # 640 frames of one group: 3 frames per workgroup, the last range ragged
+    (1, 16, 32, 32, 64),       # 16 frames: sla_out8_kernel
+    (2, 10, 16, 16, 32),
+    (1, 4, 16, 16, 128),
+]
+
+
+@pytest.mark.parametrize('case', SLA16_CASES)
+def test_sla_bf16_tensors(case):
+    from video_diffusion_nnx_amd import ops
+    B, Fr, H, W, C = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Fr, H, W, C, generator=g)
+    x[:, :, H // 2, W // 2] *= 6                                  # (a spike in the k logits: the online-softmax rescale of the first half)
+    x = x.bfloat16()
+    p = {f'a.{n}.kernel': torch.randn(1, C, 256, generator=g) / C ** 0.5 * 3 for n in ('q', 'k', 'v')}
+    p['a.to_out.kernel'] = torch.randn(1, 256, C, generator=g) / 16
+    y = ops.sla_forward_bf16(x.to(DEV), *[p[f'a.{n}.kernel'].to(DEV) for n in ('q', 'k', 'v', 'to_out')])
+    xd = x.double()
+    o = R.spatial_linear_attention({k: v.bfloat16().double() for k, v in p.items()}, 'a', xd, 8)
+    yd = y.cpu().double()
+    assert torch.isfinite(yd).all()
+    rel_branch, rel = _rel(yd - xd, o), _rel(yd, o + xd)
+    print(f'SLA on bf16 tensors {case}: branch {rel_branch:.3e}, block {rel:.3e}')
+    assert rel_branch < 4e-2 and rel < 1e-2, (case, rel_branch, rel)
+    y2 = ops.sla_forward_bf16(x.to(DEV), *[p[f'a.{n}.kernel'].to(DEV) for n in ('q', 'k', 'v', 'to_out')])
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16'])
 @pytest.mark.parametrize('case', SLA_CASES)
 def test_sla(mode, case):

@@ -89,5 +89,6 @@ vdx_time_mlp = _sig('vdx_time_mlp', c_int, [c_void_p] * 5 + [c_int, c_void_p, c_
 vdx_attention_forward = _sig('vdx_attention_forward', c_int, [c_int] + [c_void_p] * 6 + [c_int] * 7 + [c_void_p])
 vdx_attention_forward_ex = _sig('vdx_attention_forward_ex', c_int, [c_int] + [c_void_p] * 6 + [c_int] * 8 + [c_void_p])
 vdx_attention_forward_bf16 = _sig('vdx_attention_forward_bf16', c_int, [c_void_p] * 6 + [c_int] * 8 + [c_void_p])
+vdx_sla_forward_bf16 = _sig('vdx_sla_forward_bf16', c_int, [c_void_p] * 7 + [c_int] * 6 + [c_void_p])
 vdx_sla_workspace_bytes = _sig('vdx_sla_workspace_bytes', c_size_t, [c_int] * 4)
 vdx_sla_forward = _sig('vdx_sla_forward', c_int, [c_int] + [c_void_p] * 7 + [c_int] * 6 + [c_void_p])

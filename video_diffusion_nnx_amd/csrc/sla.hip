@@ -728,6 +728,189 @@ __global__ __launch_bounds__(512, NKT == 1 ? 4 : 2) void sla_out8_kernel(const S
     }
 }
 
+// ---- C = 64, bf16 tensors, >= 128 frames: the second half of the block with one WAVE per 64 pixels, all heads in the wave ("sla_out_w") ----
+// sla_out8_kernel (one wave per head) moves everything through LDS: the x tile, the per-head outputs (os), the out tile (ys), two barriers per
+// 64 pixels -- LDS array 47 % active with 39 % bank conflicts, 40 % of wave life parked (profiles/r03_pmc_step.md).  The scheme of
+// attention_w_kernel applies: a persistent workgroup per CU keeps Wq (256 x 64 bf16 = 32 KB) and the to_out image (64 x 256 = 32 KB, rows and K
+// permuted as there) in LDS and walks whole frames; the context of the current frame (8 heads x 32 x 32 bf16 = 16 KB, written by the first
+// half) sits in a double-buffered LDS image, ONE barrier per frame.  Each wave owns groups of 64 pixels: x rows straight into B fragments (one
+// group ahead; they are the residual), per head q^T = Wq_h x^T (16 MFMAs), softmax over the head's 32 channels in the accumulators, out^T =
+// ctx^T q as K = 16 MFMAs on the accumulators, its result packed as the B fragment of the to_out MFMAs -- no activation byte in LDS.
+template <int DUMMY = 0>
+__global__ __launch_bounds__(512) void sla_out_w_kernel(const SlaArgs P, const int frames_per_block) {
+    using M = Mma<MODE_BF16>;
+    constexpr int HD = 256, CRS = 72;                  // ctx image row stride (bytes): 32 d x 2 + 8 (b64 reads of 16 rows: at most 2-way conflicts)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Wq = smem;                                   // [256 rows][128 B]: 16-byte chunk c of row r at r * 128 + 16 * (c ^ (r & 7))
+    char* Wo = Wq + HD * 128;                          // [64 rows][512 B]: as attention_w_kernel
+    char* Cx = Wo + 64 * 512;                          // [2][256 rows (h * 32 + e)][CRS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lp = lane & 15, q = lane >> 4;
+    const int f0 = blockIdx.x * frames_per_block, f1 = min(f0 + frames_per_block, P.NF);
+    if (f0 >= f1) return;
+
+    for (int i = tid; i < HD * 8; i += 512) {
+        const int r = i >> 3, c = i & 7;
+        *reinterpret_cast<uint4*>(Wq + r * 128 + 16 * (c ^ (r & 7))) = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.wq) + (size_t)r * 128 + c * 16);
+    }
+    for (int i = tid; i < 64 * 32; i += 512) {
+        const int R = i >> 5, c = i & 31, hh = c >> 2, qq = c & 3;
+        const int tile = R >> 4, ri = R & 15;
+        const int co = 32 * (tile >> 1) + 8 * (ri >> 2) + 4 * (tile & 1) + (ri & 3);
+        const char* src = reinterpret_cast<const char*>(P.wo) + (size_t)co * 512 + hh * 64 + qq * 8;
+        const uint2 lo = *reinterpret_cast<const uint2*>(src), hi = *reinterpret_cast<const uint2*>(src + 32);
+        *reinterpret_cast<uint4*>(Wo + R * 512 + 16 * (c ^ (R & 15))) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+    // context image of frame f into buffer par: 256 rows x 64 bytes = 1024 pieces of 16 bytes, two per thread
+    auto load_ctx = [&](int f, int par) __attribute__((always_inline)) {
+        const char* src = reinterpret_cast<const char*>(P.ctxT) + (size_t)f * (8 * 32 * 32 * 2);
+        uint4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) v[u] = *reinterpret_cast<const uint4*>(src + (size_t)(tid + 512 * u) * 16);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = tid + 512 * u, row = i >> 2, pc = i & 3;
+            char* d = Cx + par * (256 * CRS) + row * CRS + pc * 16;
+            *reinterpret_cast<uint2*>(d) = make_uint2(v[u].x, v[u].y);
+            *reinterpret_cast<uint2*>(d + 8) = make_uint2(v[u].z, v[u].w);
+        }
+    };
+    load_ctx(f0, 0);
+    __syncthreads();                                   // weights + the first context visible
+
+    const int gpf = P.N >> 6;                          // groups of 64 pixels per frame
+    const char* const xg = reinterpret_cast<const char*>(P.x);
+    char* const yg = reinterpret_cast<char*>(P.y);
+    const unsigned loff = (unsigned)(lp * 64 + q * 8) * 2u;          // this lane's bytes inside a 16-pixel tile: pixel lp, channels 8 q ..
+    int wqo[2];
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch) wqo[ch] = lp * 128 + 16 * ((ch * 4 + q) ^ (lp & 7));
+    const int woo = lp * 512;
+
+    // the groups of this wave, frame by frame: (f, g) with g = wave_u, wave_u + 8, ...; `next` walks one group ahead for the prefetch
+    uint4 xn[4][2];
+    auto fetch = [&](int f, int g) __attribute__((always_inline)) {
+        const char* p = xg + ((size_t)f * P.N + (size_t)g * 64) * 128 + loff;
+#pragma unroll
+        for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) xn[tn][ch] = *reinterpret_cast<const uint4*>(p + tn * (16 * 128) + ch * 64);
+    };
+    uint4 wcur[2][2], wnext[2][2];
+    auto rd = [&](uint4 (&w)[2][2], const char* base) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch) w[ch][t] = *reinterpret_cast<const uint4*>(base + t * 16 * 128 + wqo[ch]);
+    };
+    rd(wcur, Wq);
+    if (wave_u < gpf) fetch(f0, wave_u);
+    for (int f = f0; f < f1; ++f) {
+        const int par = (f - f0) & 1;
+        if (f + 1 < f1) load_ctx(f + 1, par ^ 1);     // (the other buffer was last read before the previous frame's barrier)
+        const char* cimg = Cx + par * (256 * CRS);
+        for (int g = wave_u; g < gpf; g += 8) {
+            uint4 xc[4][2];
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn) { xc[tn][0] = xn[tn][0]; xc[tn][1] = xn[tn][1]; }
+            if (g + 8 < gpf) fetch(f, g + 8);
+            else if (f + 1 < f1 && wave_u < gpf) fetch(f + 1, wave_u);
+            f32x4 yacc[4][4];                          // [pixel tile][channel tile = 2 wc + tm]
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int tile = 0; tile < 4; ++tile) yacc[tn][tile] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int h = 0; h < 8; ++h) {
+                // q^T[d, px] of this head (fragments in wcur); the to_out fragments go to wnext meanwhile
+                f32x4 acc[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                {
+                    const char* woh = Wo + woo + 16 * ((4 * h + q) ^ lp);
+#pragma unroll
+                    for (int tile = 0; tile < 4; ++tile) wnext[tile >> 1][tile & 1] = *reinterpret_cast<const uint4*>(woh + tile * 8192);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 4; ++tn) M::mma(acc[tm][tn], wcur[ch][tm], xc[tn][ch]);
+                // ctx^T fragments of this head: A operand of the K = 16 product, lane (e = lp, q): d = dt * 16 + 4q .. + 3 (4 bf16)
+                uint2 cf[2][2];
+#pragma unroll
+                for (int et = 0; et < 2; ++et)
+#pragma unroll
+                    for (int dt = 0; dt < 2; ++dt) cf[et][dt] = *reinterpret_cast<const uint2*>(cimg + (h * 32 + et * 16 + lp) * CRS + dt * 32 + q * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                rd(wcur, Wq + ((h + 1) & 7) * (32 * 128));     // the next head's (head 0 of the next group after head 7) q fragments
+                // softmax over the 32 channels of the head, per pixel (lane (px, q) holds d = 16 tm + 4q + r)
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    float mx = -1e30f;
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc[tm][tn][r]);
+                    mx = max_q(mx);
+                    const float nmx = -mx * 1.44269504088896f;
+                    float sum = 0.f;
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { acc[tm][tn][r] = __builtin_amdgcn_exp2f(fmaf(acc[tm][tn][r], 1.44269504088896f, nmx)); sum += acc[tm][tn][r]; }
+                    const float inv = __builtin_amdgcn_rcpf(reduce_q(sum));
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[tm][tn][r] *= inv;
+                }
+                // out^T[e, px] = sum_d ctx^T[e, d] q[d, px]; lane (px, q): e = 16 et + 4q + r -> the to_out B fragment (K slots in accumulator order)
+                uint4 of[4];
+#pragma unroll
+                for (int tn = 0; tn < 4; ++tn) {
+                    f32x4 o[2];
+#pragma unroll
+                    for (int et = 0; et < 2; ++et) {
+                        o[et] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) {
+                            const uint2 qb = make_uint2(pack_bf16x2(acc[dt][tn][0], acc[dt][tn][1]), pack_bf16x2(acc[dt][tn][2], acc[dt][tn][3]));
+                            o[et] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, cf[et][dt]), __builtin_bit_cast(s16x4, qb), o[et], 0, 0, 0);
+                        }
+                    }
+                    of[tn] = make_uint4(pack_bf16x2(o[0][0], o[0][1]), pack_bf16x2(o[0][2], o[0][3]), pack_bf16x2(o[1][0], o[1][1]), pack_bf16x2(o[1][2], o[1][3]));
+                }
+#pragma unroll
+                for (int tile = 0; tile < 4; ++tile)
+#pragma unroll
+                    for (int tn = 0; tn < 4; ++tn) M::mma(yacc[tn][tile], wnext[tile >> 1][tile & 1], of[tn]);
+            }
+            // + residual (the fetched rows), two 16-byte stores per pixel
+            char* yp = yg + ((size_t)f * P.N + (size_t)g * 64) * 128 + loff;
+#pragma unroll
+            for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+                for (int wc = 0; wc < 2; ++wc) {
+                    const uint4 r = xc[tn][wc];
+                    const f32x4 a0 = yacc[tn][2 * wc], a1 = yacc[tn][2 * wc + 1];
+                    uint4 w;
+                    w.x = pack_bf16x2(a0[0] + __uint_as_float(r.x << 16), a0[1] + __uint_as_float(r.x & 0xFFFF0000u));
+                    w.y = pack_bf16x2(a0[2] + __uint_as_float(r.y << 16), a0[3] + __uint_as_float(r.y & 0xFFFF0000u));
+                    w.z = pack_bf16x2(a1[0] + __uint_as_float(r.z << 16), a1[1] + __uint_as_float(r.z & 0xFFFF0000u));
+                    w.w = pack_bf16x2(a1[2] + __uint_as_float(r.w << 16), a1[3] + __uint_as_float(r.w & 0xFFFF0000u));
+                    *reinterpret_cast<uint4*>(yp + tn * (16 * 128) + wc * 64) = w;
+                }
+        }
+        __syncthreads();                               // the next frame's context is visible; everybody is done with this one
+    }
+}
+
 // ---- wide levels (C >= 256): one workgroup per (head, chunk of frames), one wave per frame ------------------------------------------
 // The head's q/k/v weight rows (96 x C bf16) are loaded into LDS once per workgroup; each wave then owns whole frames and needs no
 // workgroup barrier, no partials and no combine pass: phase 1 walks the frame's pixels in steps of 16*TT with the k/v projections
@@ -967,6 +1150,28 @@ static hipError_t launch_sla_out_t(const SlaArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
+#ifndef VDX_SLA_W
+#define VDX_SLA_W 1
+#endif
+static bool sla_out_w_eligible(const SlaArgs& a) {
+    return VDX_SLA_W && a.io_bf16 && a.C == 64 && a.CPad == 64 && a.heads == 8 && a.N % 64 == 0 && a.NF >= 128 && (size_t)a.NF * a.N * 128 < (1ull << 40);
+}
+static hipError_t launch_sla_out_w(const SlaArgs& a, hipStream_t st) {
+    const size_t lds = 256 * 128 + 64 * 512 + 2 * 256 * 72;
+    auto kfn = sla_out_w_kernel<0>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
+    const int blocks0 = std::min(a.NF, cus);
+    const int fpb = (a.NF + blocks0 - 1) / blocks0;
+    const int blocks = (a.NF + fpb - 1) / fpb;
+    const SlaWork sw = sla_work(a, 2, false, true, true);
+    LaunchScope ls(st, "sla_out_w_kernel", sw.flops, sw.bytes, "C%d N%d NF%d", a.C, a.N, a.NF);
+    hipLaunchKernelGGL(kfn, dim3(blocks), dim3(512), lds, st, a, fpb);
+    return hipGetLastError();
+}
+
 template <int MODE, int NKT, int TMO, int TNO, bool IO16>
 static hipError_t launch_sla8_t(const SlaArgs& a, hipStream_t st) {
     using M = Mma<MODE>;
@@ -988,6 +1193,9 @@ static hipError_t launch_sla8_t(const SlaArgs& a, hipStream_t st) {
         LaunchScope ls(st, "sla_combine_kernel", 0.0, (double)a.NF * a.nchunk * a.heads * SLA_PART * 4, "<%d> NF%d nchunk%d", MODE, a.NF, a.nchunk);
         hipLaunchKernelGGL(sla_combine_kernel<MODE>, dim3(a.NF * a.heads), dim3(256), 0, st, a.part, a.ctxT, a.nchunk, a.heads);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if constexpr (MODE == MODE_BF16 && IO16 && NKT == 1 && TNO == 2) {
+        if (sla_out_w_eligible(a)) return launch_sla_out_w(a, st);      // C = 64, many frames: one wave per 64 pixels
     }
     const SlaWork sw = sla_work(a, M::ES, false, true, true);
     LaunchScope ls(st, "sla_out8_kernel", sw.flops, sw.bytes, "<%d, %d, %d, %d, %d> C%d N%d NF%d", MODE, NKT, TMO, TNO, (int)IO16, a.C, a.N, a.NF);

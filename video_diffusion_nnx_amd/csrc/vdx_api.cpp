@@ -261,6 +261,19 @@ int vdx_sla_forward(int mode, const float* x, float* y, const void* wq_packed, c
     return VDX_OK;
 }
 
+int vdx_sla_forward_bf16(const void* x_bf16, void* y_bf16, const void* wq_packed, const void* wk_packed, const void* wv_packed,
+                         const void* wo_packed, void* workspace, int batch, int frames, int h, int w, int c, int heads, void* stream) {
+    if (!x_bf16 || !y_bf16 || !wq_packed || !wk_packed || !wv_packed || !wo_packed || !workspace) VDX_FAIL(VDX_ERR_INVALID, "sla: null tensor");
+    if (heads != 8 || c % 8 || c > 1024) VDX_FAIL(VDX_ERR_INVALID, "sla (bf16 tensors): needs 8 heads, C multiple of 8 and <= 1024");
+    vdx::SlaArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = reinterpret_cast<const float*>(x_bf16); a.y = reinterpret_cast<float*>(y_bf16); a.io_bf16 = 1;
+    a.wq = wq_packed; a.wk = wk_packed; a.wv = wv_packed; a.wo = wo_packed; a.workspace = workspace;
+    a.C = c; a.heads = heads; a.NF = batch * frames; a.N = h * w;
+    VDX_HIP(vdx::launch_sla(VDX_MODE_BF16, a, (hipStream_t)stream));
+    return VDX_OK;
+}
+
 int vdx_create(const vdx_config* cfg, vdx_handle** out) {
     if (!cfg || !out) VDX_FAIL(VDX_ERR_INVALID, "create: null argument");
     if (cfg->mode != VDX_MODE_F32 && cfg->mode != VDX_MODE_BF16 && cfg->mode != VDX_MODE_F16) VDX_FAIL(VDX_ERR_INVALID, "bad mode");

@@ -157,6 +157,19 @@ def sla_forward(x, wq, wk, wv, wo, heads, mode):
     return y
 
 
+def sla_forward_bf16(x, wq, wk, wv, wo, heads=8):
+    """x: bf16 channel-last [B, F, H, W, C]; wq/wk/wv: Flax (1, C, 256); wo: (1, 256, C)."""
+    assert x.dtype == torch.bfloat16 and x.is_contiguous()
+    B, Fr, H, W, C_ = x.shape
+    m = _mode('bf16')
+    y = torch.empty_like(x)
+    ws = torch.empty(L.vdx_sla_workspace_bytes(m, B * Fr, H * W, heads), dtype=torch.uint8, device=x.device)
+    pk = [pack_conv_weights(t, 'bf16') for t in (wq, wk, wv, wo)]
+    L.check(L.vdx_sla_forward_bf16(L.ptr(x), L.ptr(y), L.ptr(pk[0]), L.ptr(pk[1]), L.ptr(pk[2]), L.ptr(pk[3]), L.ptr(ws),
+                                   B, Fr, H, W, C_, heads, L.stream_ptr()))
+    return y
+
+
 # ---- backward building blocks ---------------------------------------------------------------------------
 
 
