@@ -341,6 +341,10 @@ WS4_CASES = [
     (1, 2, 16, 32, 64, 64),            # level-1 -> 0 Upsample: 32 -> 64, bands of 8 x 32 input pixels x 4 phases
     (0, 3, 12, 64, 128, 128),          # bands with a 128-channel output tile, 2 K chunks per plane, 144 tiles (ragged)
     (1, 8, 16, 16, 128, 64),           # whole 16 x 16 frames with a 64-channel output tile
+    (0, 3, 10, 64, 32, 32),            # resample32_kernel (dim-32 networks, level 0): Downsample 64 -> 32, everything in registers
+    (1, 3, 10, 32, 32, 32),            # resample32_kernel: Upsample 32 -> 64 (four output phases from the 3 x 3 neighbourhood)
+    (0, 1, 3, 32, 32, 32),             # ragged: 48 tiles over 48 waves
+    (1, 1, 3, 16, 32, 32),
 ]
 
 

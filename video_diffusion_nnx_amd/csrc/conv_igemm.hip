@@ -1901,6 +1901,11 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st) {
         LaunchScope ls(st, "conv4x4_ws_kernel", cw.flops, cw.bytes, "<%d, %d, %d> %s", a.kind == 1 ? a.H : a.H / 2, a.kind == 1 ? 2 : 1, a.Cout == 64 ? 64 : 128, cw.shape);
         return launch_conv4x4_ws(a, st);
     }
+    if (resample32_eligible(mode, a)) {                                      // 32-channel resampling convs (level 0 of dim-32 networks)
+        const ConvWork cw = conv_work(mode, a);
+        LaunchScope ls(st, "resample32_kernel", cw.flops, cw.bytes, "<%d> %s", a.kind, cw.shape);
+        return launch_resample32(a, st);
+    }
     if (conv1x1_pw_eligible(mode, a)) {                                      // 1x1 convs of the wide levels (bf16 tensors)
         const ConvWork cw = conv_work(mode, a);
         LaunchScope ls(st, "conv1x1_pw_kernel", cw.flops, cw.bytes, "<%d> %s", conv1x1_pw_rows(a), cw.shape);
