@@ -211,6 +211,8 @@ WS_CASES = [
     (8, 16, 8, 512, 0, 512),           # level-3 / mid shape: four whole 8 x 8 frames per tile, four output-channel tiles, ring of 3
     (8, 8, 8, 256, 0, 128),            # F = 8: two tiles per sample
     (16, 16, 8, 512, 512, 256),        # ups.0 block1: 1024 -> 256 on a concat input, two output-channel tiles, 16 K chunks
+    (22, 10, 8, 256, 0, 256),          # F = 10 (config_v2_2 as written) at 8 x 8: per-sample tiles of 4, 4 and 2 frames (the last one partly filled)
+    (6, 6, 16, 128, 0, 256),           # F = 6 at 16 x 16: one frame per tile
 ]
 
 

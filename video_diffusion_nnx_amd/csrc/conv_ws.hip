@@ -94,7 +94,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
     const int nchunks = P.CinPad >> 6;
     const int Cin = P.C0 + P.C1;
     const int fpt = NP;                                   // frames per tile
-    auto sample_of = [&](int t) { return WF ? (t * fpt) / P.F : (t / tiles_pf) / P.F; };
+    // whole-frame geometries tile PER SAMPLE: tps = ceil(F / NP) tiles, the last one of a sample only partly filled when NP does not divide
+    // F (F = 10, the YAML-literal config_v2_2, at 8 x 8: tiles of 4, 4, 2 frames) -- its missing pixel rows read the zero page, are
+    // not stored and stay out of the statistics; a tile never straddles two samples (per-sample prologue coefficients and statistics)
+    const int tps = WF ? (P.F + NP - 1) / NP : 1;
+    auto sample_of = [&](int t) { return WF ? t / tps : (t / tiles_pf) / P.F; };
+    auto wf_pix0 = [&](int t) { const int b = t / tps, k = t - b * tps; return (unsigned)(b * P.F + k * NP) * (unsigned)(S * S); };   // first pixel row of tile t
+    auto wf_rows = [&](int t) { const int k = t % tps; return min(NP, P.F - k * NP) * (S * S); };                                  // pixel rows the tile holds
 
     // ---- per-thread constants -----------------------------------------------------------------------------------------
     // weight stream: this thread's two 16-byte pieces of a slab
@@ -171,12 +177,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
         okmask = 0;
         const int l = opaque_lane();
         if (WF) {
-            const unsigned pix0 = (unsigned)t * 256u;     // a tile = 256 consecutive pixel rows of the tensor (tensors < 4 GB: launcher)
+            const unsigned pix0 = wf_pix0(t);             // a tile = up to 256 consecutive pixel rows of the tensor (tensors < 4 GB: launcher)
+            const int nrows = wf_rows(t);
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
                 int row, ch;
                 if (piece(u, l, row, ch)) {
-                    const bool ok = row < 256;            // row 256 = the zero row
+                    const bool ok = row < nrows;          // row 256 = the zero row; rows past the sample's last frame read zeros too
                     const unsigned off = ((pix0 + row) * Cs + cb + (ch << 3)) * 2u;
                     const void* src = ok ? static_cast<const void*>(xb + off) : static_cast<const void*>(zero_page);
                     glds16(src, dst + u * 8 * 1024);
@@ -376,7 +383,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
             const int b = sample_of(t);
             if (b != bcur) { flush_stats(bcur); bcur = b; }
             size_t tile_pix;
-            if (WF) tile_pix = (size_t)t * 256;
+            int nrows = 256;
+            if (WF) { tile_pix = wf_pix0(t); nrows = wf_rows(t); }
             else { const int f = t / tiles_pf, rem = t - f * tiles_pf, ty = rem / tiles_x, tx = rem - ty * tiles_x;
                    tile_pix = ((size_t)f * P.H + (size_t)ty * 16) * P.W + (size_t)tx * 16; }
             const int cobase = j * 128 + wc * 64 + 4 * q;
@@ -386,6 +394,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(const ConvArgs P, co
                 const float4 bs = *reinterpret_cast<const float4*>(biasl + wc * 64 + tm * 16 + 4 * q);
 #pragma unroll
                 for (int tn = 0; tn < 4; ++tn) {
+                    if (WF && opix[tn] >= nrows) continue;                 // (a partly filled last tile of a sample)
                     const float4 v = make_float4(acc[tm][tn][0] + bs.x, acc[tm][tn][1] + bs.y, acc[tm][tn][2] + bs.z, acc[tm][tn][3] + bs.w);
                     const size_t e = (tile_pix + opix[tn]) * P.Cout + cobase + tm * 16;
                     if (P.y_bf16) *reinterpret_cast<uint2*>(reinterpret_cast<char*>(P.y) + e * 2) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
@@ -634,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void conv4x4_ws_kernel(const ConvArgs P, co
 // ---- host side ----------------------------------------------------------------------------------------------------------
 
 static int ws_geo(const ConvArgs& a) {                    // 0: 16 x 16 tiles, 8 / 16: whole frames, -1: not served
-    if (a.H == 8 && a.W == 8 && a.F % 4 == 0) return 8;
+    if (a.H == 8 && a.W == 8) return 8;                   // (4 frames per tile; F % 4 != 0: the last tile of a sample is partly filled)
     if (a.H == 16 && a.W == 16) return 16;
     if (a.H % 16 == 0 && a.W % 16 == 0) return 0;
     return -1;
@@ -703,9 +712,11 @@ bool conv3x3_ws_eligible(int mode, const ConvArgs& a) {
     if (a.wrows != a.Cout || a.wrow0 != 0) return false;
     const int geo = ws_geo(a);
     if (geo < 0) return false;
+    if (geo != 0 && (a.F <= 0 || a.NF % a.F)) return false;        // whole-frame tiles are laid out per sample
     if (a.pro && (a.C1 || a.groups < 1 || a.groups > 32 || a.C0 % a.groups || a.C0 > 1024)) return false;
     if (a.out_stats && (a.out_groups < 1 || a.Cout % a.out_groups || (a.Cout / a.out_groups) % 16)) return false;
-    const long tiles = geo == 0 ? (long)a.NF * (a.H / 16) * (a.W / 16) : (long)a.NF * a.H * a.W / 256;
+    const int npf = geo == 0 ? 1 : 256 / (a.H * a.W);         // frames per whole-frame tile; tiles per sample = ceil(F / npf)
+    const long tiles = geo == 0 ? (long)a.NF * (a.H / 16) * (a.W / 16) : (long)(a.NF / a.F) * ((a.F + npf - 1) / npf);
     if (tiles * nct < 128) return false;                 // too few tiles to feed the chip from persistent workgroups: generic kernel
     if ((size_t)a.NF * a.H * a.W * (size_t)std::max(a.C0, a.C1) * 2 >= 0xFFFF0000ull) return false;     // 32-bit byte offsets
     return true;
@@ -714,7 +725,8 @@ bool conv3x3_ws_eligible(int mode, const ConvArgs& a) {
 hipError_t launch_conv3x3_ws(const ConvArgs& a, hipStream_t st) {
     const int geo = ws_geo(a);
     const int nct = a.Cout / 128;
-    const int total = geo == 0 ? a.NF * (a.H / 16) * (a.W / 16) : (int)((long)a.NF * a.H * a.W / 256);
+    const int npf = geo == 0 ? 1 : 256 / (a.H * a.W);
+    const int total = geo == 0 ? a.NF * (a.H / 16) * (a.W / 16) : (a.NF / a.F) * ((a.F + npf - 1) / npf);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v; }
     const int unit = 8 * nct;                             // the decode deals ranges to the 8 XCDs
