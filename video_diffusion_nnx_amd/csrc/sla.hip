@@ -1153,8 +1153,12 @@ static hipError_t launch_sla_out_t(const SlaArgs& a, hipStream_t st) {
 #ifndef VDX_SLA_W
 #define VDX_SLA_W 1
 #endif
+#ifndef VDX_SLA_W_MIN_N
+#define VDX_SLA_W_MIN_N 2048
+#endif
 static bool sla_out_w_eligible(const SlaArgs& a) {
-    return VDX_SLA_W && a.io_bf16 && a.C == 64 && a.CPad == 64 && a.heads == 8 && a.N % 64 == 0 && a.NF >= 128 && (size_t)a.NF * a.N * 128 < (1ull << 40);
+    // (frames of 1024 pixels = 2 groups per wave and frame: the per-frame context load + barrier cost more than the staging they replace: 103 vs 90 us)
+    return VDX_SLA_W && a.io_bf16 && a.C == 64 && a.CPad == 64 && a.heads == 8 && a.N % 64 == 0 && a.N >= VDX_SLA_W_MIN_N && a.NF >= 128 && (size_t)a.NF * a.N * 128 < (1ull << 40);
 }
 static hipError_t launch_sla_out_w(const SlaArgs& a, hipStream_t st) {
     const size_t lds = 256 * 128 + 64 * 512 + 2 * 256 * 72;
@@ -1213,7 +1217,10 @@ static hipError_t launch_sla_m(SlaArgs a, hipStream_t st) {
     // traffic (8 x 4.4 KB per chunk, written here and re-read by the combine) per doubling
     {
         const int tiles = (a.N + 63) / 64;
-        const long min_wgs = 1024;
+#ifndef VDX_SLA_MIN_WGS
+#define VDX_SLA_MIN_WGS 1024
+#endif
+        const long min_wgs = VDX_SLA_MIN_WGS;
         while (a.nsub * 2 <= tiles && (long)a.NF * ((tiles + 2 * a.nsub - 1) / (2 * a.nsub)) >= min_wgs) a.nsub *= 2;
         a.nchunk = (tiles + a.nsub - 1) / a.nsub;
     }
