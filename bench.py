@@ -385,7 +385,11 @@ def main():
                            'tflops': world * B * 54.09e9 / (yms * 1e-3) / 1e12, 'n_shape_tflops': world * B * 250.77e9 / (ms_per_step * 1e-3) / 1e12}
         log(f"Y shape: {yms:.3f} ms/step, {line['y_shape']['frames_per_s']:.1f} frames/s")
     if rank == 0 and not args.no_other_configs:
-        line['other_configs'] = other_configs_leg(dev, world)
+        try:                                              # secondary object: a failure here must not cost the line its primary fields
+            line['other_configs'] = other_configs_leg(dev, world)
+        except Exception as e:                            # noqa: BLE001
+            line['other_configs'] = {'error': f'{type(e).__name__}: {e}'}
+            log(f'other_configs leg failed: {e}')
     if not args.no_train:
         log('training leg (p_losses fwd+bwd + bucketed all-reduce + Adam/EMA) ...')
         line['train'] = train_leg(args, dev, world, rank)         # every rank takes part (collectives inside)
