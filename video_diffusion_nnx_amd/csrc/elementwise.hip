@@ -140,6 +140,59 @@ __global__ __launch_bounds__(256) void resblock_tail16_kernel(TailArgs P) {
     }
 }
 
+// ---- the Block prologue as its own pass: y <- SiLU(GroupNorm(y) * (scale + 1) + shift), in place on a bf16 tensor -------------------------
+// conv3x3_ws_kernel's fused-prologue forms re-do this arithmetic in each of the Cout / 128 workgroups of a pixel range, inside a kernel that is
+// bound by instruction issue: at 512 channels x 8 x 8 pixels the prologue costs 57 us per launch (313 vs 256 us at B = 64), the tensor is 67 MB
+// -- this pass moves 134 MB in ~25 us.  Used by the sampling forward (inference storage: nothing else reads y1 afterwards) where that pays
+// (model.hip run_resblock); identical values: the fused form rounds the activation to bf16 before the MFMA too.
+__global__ __launch_bounds__(256) void gn_silu_apply16_kernel(unsigned* __restrict__ y, const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ ss, int ss_stride, int groups,
+                                                              int C, long pix_per_sample) {
+    __shared__ float coefA[1024], coefD[1024];
+    __shared__ float gm[64];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    gn_mean_rstd_wg(stats, b, groups, (double)pix_per_sample * (C / groups), gm, tid, 256);
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / (C / groups);
+        const float m = gm[2 * g], rs = gm[2 * g + 1];
+        const float ga = gamma[c], be = beta[c];
+        float sc = 1.f, sh = 0.f;
+        if (ss) { sc = ss[(size_t)b * ss_stride + c] + 1.f; sh = ss[(size_t)b * ss_stride + C + c]; }
+        coefA[c] = rs * ga * sc;                              // (the expressions of conv3x3_ws_kernel's make_coef: bit-identical coefficients)
+        coefD[c] = (be - m * rs * ga) * sc + sh;
+    }
+    __syncthreads();
+    const int octs = C >> 3;
+    const long n = pix_per_sample * octs;                     // 16-byte pieces of this sample
+    uint4* base = reinterpret_cast<uint4*>(y) + (size_t)b * n;
+    for (long i0 = (long)blockIdx.x * 1024 + tid; i0 < n; i0 += (long)gridDim.x * 1024) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (i0 + u * 256 < n) ? base[i0 + u * 256] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * 256 >= n) continue;
+            const int c = (int)((i0 + u * 256) % octs) * 8;
+            float f[8], o[8];
+            unpack8(v[u], f);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = silu_f(fmaf(f[k], coefA[c + k], coefD[c + k]));
+            base[i0 + u * 256] = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
+        }
+    }
+}
+
+hipError_t launch_gn_silu_apply16(float* y_bf16, const double* stats, const float* gamma, const float* beta, const float* ss, int ss_stride, int groups,
+                                  int C, int batch, long pix_per_sample, hipStream_t st) {
+    if (C % 8 || C > 1024 || groups <= 0 || groups > 32 || C % groups) return hipErrorInvalidValue;
+    const long n = pix_per_sample * (C / 8);
+    const int gx = (int)std::max<long>(1, std::min<long>((n + 1023) / 1024, 2048));
+    LaunchScope ls(st, "gn_silu_apply16_kernel", 8.0 * batch * pix_per_sample * C, 4.0 * batch * pix_per_sample * C, "C%d px%ld x %d", C, pix_per_sample, batch);
+    hipLaunchKernelGGL(gn_silu_apply16_kernel, dim3(gx, batch), dim3(256), 0, st, reinterpret_cast<unsigned*>(y_bf16), stats, gamma, beta, ss, ss_stride, groups, C, pix_per_sample);
+    return hipGetLastError();
+}
+
 // ---- tail with the 1x1 res_conv inside (bf16 tensors, bf16 MFMA operands) ---------------------------------------------------------
 // out = SiLU(GroupNorm(y2)) + LayerNorm_C(concat(x0, x1) . W_rc + b_rc)   modules.py:219-222 (res_conv) + :240-243
 // The separate 1x1 conv read the block input (2E at level 0, a concat) and wrote r (E) for the tail to read again; here a wave takes

@@ -346,6 +346,10 @@ struct Fwd {
     double* stat(int i) const { return stats + (size_t)i * B * GN_SLOTS * m->cfg.resnet_groups * 2; }
 };
 
+#ifndef VDX_PREPASS_MIN_C
+#define VDX_PREPASS_MIN_C 256                                 // Block prologue as its own pass from this width on (sampling forward)
+#endif
+
 static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, const float* x1, int c1, int lvl) {
     const Model* m = f.m;
     const int G = m->cfg.resnet_groups;
@@ -370,6 +374,13 @@ static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, 
     b.pro = 1; b.in_stats = f.stat(r.st1); b.gamma = f.p + r.b1_gs; b.beta = f.p + r.b1_gb; b.groups = G;
     if (r.has_mlp) { b.ss = f.ss + (size_t)m->ss_layers[r.ss_index].out_off * f.B; b.ss_stride = 2 * r.cout; }
     b.out_stats = f.stat(r.st2); b.out_groups = G;
+    // sampling forward, wide blocks: the prologue as one in-place pass over y1 (nothing reads y1 after conv2 in inference storage), and the plain
+    // form of the weight-stationary conv -- its fused-prologue form repeats the GroupNorm / SiLU arithmetic in each of its Cout / 128 workgroups
+    if (half && m->act16 == 1 && r.cout >= VDX_PREPASS_MIN_C) {
+        e = launch_gn_silu_apply16(f.slot(r.s_y1), b.in_stats, b.gamma, b.beta, b.ss, b.ss_stride, G, r.cout, f.B, (long)m->cfg.num_frames * S * S, f.st);
+        if (e != hipSuccess) return e;
+        b.pro = 0; b.in_stats = nullptr; b.gamma = b.beta = nullptr; b.ss = nullptr; b.groups = 0;
+    }
     e = launch_conv(m->mode, b, f.st);
     if (e != hipSuccess) return e;
     const float* rsrc = x0;

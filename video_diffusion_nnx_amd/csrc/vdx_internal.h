@@ -261,6 +261,9 @@ hipError_t launch_conv(int mode, ConvArgs a, hipStream_t st);
 int conv3x3_ws_geo(const ConvArgs& a);
 bool conv4x4_ws_eligible(int mode, const ConvArgs& a);     // Downsample / Upsample of the wide levels on the weight-streaming machinery
 hipError_t launch_conv4x4_ws(const ConvArgs& a, hipStream_t st);       // 0 / 8 / 16: the GEO template argument launch_conv3x3_ws will use
+// y <- SiLU(GroupNorm(y) * (scale + 1) + shift) in place on a bf16 tensor [batch][pix][C] (the Block prologue as its own pass; elementwise.hip)
+hipError_t launch_gn_silu_apply16(float* y_bf16, const double* stats, const float* gamma, const float* beta, const float* ss, int ss_stride, int groups,
+                                  int C, int batch, long pix_per_sample, hipStream_t st);
 bool resample32_eligible(int mode, const ConvArgs& a);      // Downsample / Upsample of 32-channel bf16 tensors (dim-32 networks): everything in registers (conv_rs.hip)
 hipError_t launch_resample32(const ConvArgs& a, hipStream_t st);
 bool conv1x1_pw_eligible(int mode, const ConvArgs& a);     // 1x1 convs of the wide levels on bf16 tensors: weight rows resident in LDS, x straight into fragments (conv_pw.hip)
