@@ -23,7 +23,7 @@ def main():
     gd = GaussianDiffusion(unet, image_size=a.size, num_frames=a.frames, channels=1, timesteps=1000, loss_type='l2')
     tmp = tempfile.mkdtemp()
     tr = Trainer(gd, tmp, dataset_path='synthetic:64', train_batch_size=a.batch * world, train_num_steps=10 ** 9, results_folder=tmp)
-    x = torch.rand(a.batch, 1, a.frames, a.size, a.size)
+    x = torch.rand(a.batch, 1, a.frames, a.size, a.size).to(torch.device('cuda', local))      # resident, as bench.py's train leg
     for i in range(2):
         tr.train_step(x, i)
     torch.cuda.synchronize()

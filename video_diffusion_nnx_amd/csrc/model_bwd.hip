@@ -23,7 +23,7 @@ struct Bwd {
     // forward workspace views
     float* act; float* temb; float* ss; float* ss_lin; double* stats;
     // backward workspace views
-    std::vector<LevelBufs> lv; float* gr; float* S; float* dss; float* dtemb; float* normscr; float* sla_a;
+    std::vector<LevelBufs> lv; float* gr; float* S; float* Sbuf[2]; int s_cur = 0; float* dss; float* dtemb; float* normscr; float* sla_a;
     float* part_side; float* part_main;             // slots of the deterministic accumulations (WG_PART_FLOATS each): one per stream, used in stream order
     float* slot(int s) const { return act + (size_t)m->slots[s].offset_per_sample * B; }
     double* stat(int i) const { return stats + (size_t)i * B * GN_SLOTS * m->cfg.resnet_groups * 2; }
@@ -31,13 +31,17 @@ struct Bwd {
     int size(int lvl) const { return m->cfg.image_size >> lvl; }
     hipError_t err = hipSuccess;
     bool ok(hipError_t e) { if (e != hipSuccess && err == hipSuccess) err = e; return e == hipSuccess; }
+    // the attention scratch of the next block: two of them, used alternately -- the weight gradients of a block (side stream) read its
+    // scratch while the next block's data-gradient chain already fills the other one (one scratch: the main stream idled 60-240 us
+    // behind every attention block, ~1.1 ms per train step at the N shape)
+    float* next_scratch() { s_cur ^= 1; S = Sbuf[s_cur]; return S; }
 
     // ---- second stream ------------------------------------------------------------------------------------------------------
     // Weight gradients are leaves of the reverse graph: nothing of the pass reads them, so they run on the handle's side stream
     // beside the data-gradient chain (at batch 4 per GPU most kernels leave CUs or wave slots idle; DESIGN.md, backward).
     // Edges: a side launch waits for everything enqueued on the main stream so far (side()); the main stream waits for the side
-    // stream before it overwrites a buffer a pending side kernel reads (writes()), and at the end of every stage (join()): a
-    // stage's parameter gradients are final when the stage returns, as the data-parallel reducer assumes.
+    // stream before it overwrites a buffer a pending side kernel reads (writes()), and at the end of every call (join()): the
+    // parameter gradients of the stages a call ran are final on `st` when it returns, as the data-parallel reducer assumes.
     BwdState* state = nullptr;
     struct Pending { const void* buf; hipEvent_t done; int seq; };
     std::vector<Pending> pending;                   // buffers read by side kernels the main stream has not waited for
@@ -206,7 +210,7 @@ void attn_bwd(Bwd& b, const AttnP& ap, const float* g, const float* x, int lvl, 
     const Model* m = b.m;
     const int C = ap.C, H = m->cfg.attn_heads, HD = H * 32;
     const long npix = b.pix(lvl) * b.B;
-    float* qkv = b.S; float* dO = qkv + npix * 3 * HD; float* O = dO + npix * HD; float* dq = O + npix * HD;      // [npix][dq | dk | dv]
+    float* qkv = b.next_scratch(); float* dO = qkv + npix * 3 * HD; float* O = dO + npix * HD; float* dq = O + npix * HD;      // [npix][dq | dk | dv]
     // bf16 mode, <= 16 tokens: qkv, dO, O and dq|dk|dv are bf16 tensors (the MFMA core is bound by this traffic); the buffers keep
     // their fp32-sized places in the scratch
     const long hw = (long)b.size(lvl) * b.size(lvl), Fr = m->cfg.num_frames;
@@ -246,7 +250,7 @@ void sla_bwd(Bwd& b, const SlaP& sp, const float* g, const float* x, int lvl, fl
     const Model* m = b.m;
     const int C = sp.C, HD = m->cfg.attn_heads * 32;
     const long npix = b.pix(lvl) * b.B;
-    float* q = b.S; float* k = q + npix * HD; float* v = k + npix * HD; float* dOut = v + npix * HD; float* O = dOut + npix * HD;
+    float* q = b.next_scratch(); float* k = q + npix * HD; float* v = k + npix * HD; float* dOut = v + npix * HD; float* O = dOut + npix * HD;
     float* dq = O + npix * HD;      // [npix][dq | dk | dv]
     const int io16 = (m->mode == MODE_BF16) ? 1 : 0;      // bf16 mode: q, k, v, dOut, O and dq|dk|dv are bf16 tensors in fp32-sized scratch places
     b.writes(b.S);
@@ -274,7 +278,10 @@ float* other(const LevelBufs& L, const float* cur) { return cur == L.ga ? L.gb :
 // all-reduces a bucket as soon as its last stage has been enqueued); d(temb) accumulates across stages and is consumed by the stem.
 void ss_bwd(Bwd& b, int first, int count) {
     if (first < 0 || count <= 0) return;
-    b.ok(launch_resblock_ss_bwd(b.p, b.grads, b.temb, b.m->d_ss_layers + first, count, b.ss_lin, b.dss, b.dtemb, b.m->temb_dim, b.B, b.writes(nullptr), b.part_main, WG_PART_FLOATS));
+    // leaves of the reverse graph (parameter gradients and d(temb), which only the stem's time-MLP backward reads -- on the same stream):
+    // side stream, in order behind the weight gradients of the stage (main stream: 3 launches of 2-4 workgroups per stage, ~0.4 ms per step)
+    b.ok(launch_resblock_ss_bwd(b.p, b.grads, b.temb, b.m->d_ss_layers + first, count, b.ss_lin, b.dss, b.dtemb, b.m->temb_dim, b.B, b.side(), b.part_side, WG_PART_FLOATS));
+    b.side_done(b.dss);
 }
 
 }  // namespace
@@ -306,7 +313,7 @@ size_t model_bwd_workspace_bytes(const Model* m, int B) {
     }
     const size_t pix0 = (size_t)B * m->cfg.num_frames * m->cfg.image_size * m->cfg.image_size;
     fl += al(pix0 * m->init_dim);                                  // gr
-    fl += al(pix0 * (size_t)(m->cfg.attn_heads * 32) * 8);         // S
+    fl += 2 * al(pix0 * (size_t)(m->cfg.attn_heads * 32) * 8);     // S (two, alternating per attention block)
     fl += al((size_t)m->ss_floats_per_sample * B);                 // dss
     fl += al((size_t)m->temb_dim * B);                             // dtemb
     fl += al(norm_scratch_floats(m, B));                           // norm scratch
@@ -356,7 +363,8 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
         }
         const size_t pix0 = (size_t)B * c.num_frames * c.image_size * c.image_size;
         b.gr = w; w += al(pix0 * m->init_dim);
-        b.S = w; w += al(pix0 * (size_t)(c.attn_heads * 32) * 8);
+        for (int i = 0; i < 2; ++i) { b.Sbuf[i] = w; w += al(pix0 * (size_t)(c.attn_heads * 32) * 8); }
+        b.S = b.Sbuf[0];
         b.dss = w; w += al((size_t)m->ss_floats_per_sample * B);
         b.dtemb = w; w += al((size_t)m->temb_dim * B);
         b.normscr = w; w += al(norm_scratch_floats(m, B));
@@ -442,21 +450,25 @@ int model_backward(const Model* m, BwdState* state, const float* params, const v
             // stem: r gradient joins, init temporal attention, init conv, time-embedding MLPs
             LevelBufs& LB = b.lv[0];
             VDX_E(launch_add_inplace(g, b.gr, pix0 * m->init_dim, b.writes(g)));
-            float* o = other(LB, g);
-            attn_bwd(b, m->init_attn, g, b.slot(m->s_init), 0, true, o); g = o;
-            VDX_E(launch_init_conv_wgrad(x, g, grads + m->init_w, grads + m->init_b, B, c.channels, c.num_frames, c.image_size, c.image_size,
-                                         m->init_dim, c.init_kernel_size, b.side(), b.part_side, WG_PART_FLOATS));
-            b.side_done(g);
+            // d(temb) is final (every ss_bwd ran on the side stream): the time-MLP backward (a few workgroups, ~240 us) goes there too,
+            // beside the init attention's backward; the init conv's weight gradient runs on the main stream behind that attention
+            // while the side stream takes the attention's weight gradients (the pass used to end with ~380 us of one stream idle)
             TimeMlpArgs t;
             memset(&t, 0, sizeof(t));
             t.time = time; t.w1 = params + m->t_w1; t.b1 = params + m->t_b1; t.w2 = params + m->t_w2; t.b2 = params + m->t_b2;
             t.dim = c.dim; t.time_dim = m->time_dim; t.cond = cond; t.cond_mask = cond_mask; t.null_all = null_all; t.cond_dim = c.cond_dim; t.temb_dim = m->temb_dim;
             VDX_E(launch_time_mlp_bwd(t, b.dtemb, grads + m->t_w1, grads + m->t_b1, grads + m->t_w2, grads + m->t_b2,
-                                      c.cond_dim ? grads + m->null_cond : nullptr, B, b.writes(nullptr)));
+                                      c.cond_dim ? grads + m->null_cond : nullptr, B, b.side()));
+            b.side_done(b.dtemb);
+            float* o = other(LB, g);
+            attn_bwd(b, m->init_attn, g, b.slot(m->s_init), 0, true, o); g = o;
+            VDX_E(launch_init_conv_wgrad(x, g, grads + m->init_w, grads + m->init_b, B, c.channels, c.num_frames, c.image_size, c.image_size,
+                                         m->init_dim, c.init_kernel_size, b.writes(nullptr), b.part_main, WG_PART_FLOATS));
         }
-        b.join();                                                  // every gradient of the stage is final on `st`
         if (b.err != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(b.err), __FILE__, __LINE__);
     }
+    b.join();                                                      // every gradient of the stages of this call is final on `st`
+    if (b.err != hipSuccess) return vdx_set_error(VDX_ERR_HIP, hipGetErrorString(b.err), __FILE__, __LINE__);
 #undef VDX_E
     state->g = g;
     state->next_stage = stage_lo - 1;

@@ -51,7 +51,13 @@ def run_train_step(tr, batch: torch.Tensor, step: int, t: torch.Tensor = None, n
     if t is None:
         g = torch.Generator().manual_seed(t_key & 0x7FFFFFFFFFFFFFFF)
         t = torch.randint(0, gd.num_timesteps, (B,), generator=g, dtype=torch.int32)
-    t = torch.as_tensor(t).to(dev, torch.int32)
+    t = torch.as_tensor(t)
+    if t.device.type == 'cpu' and dev.type == 'cuda':
+        # (pinned + non-blocking: a pageable host-to-device copy waits for the stream to drain -- one host sync per step that kept the
+        # launch queue from running ahead of the GPU)
+        t = t.to(torch.int32).pin_memory().to(dev, non_blocking=True)
+    else:
+        t = t.to(dev, torch.int32)
     noise = gd.randn(x.shape, noise_key, 0) if noise is None else torch.as_tensor(noise).to(dev, torch.float32).contiguous()
     tr.last_t, tr.last_noise_key = t, noise_key
     x_noisy = gd.q_sample(x, t, noise=noise, _pre=(2.0, -1.0))                    # normalize_img folded in (:499)
@@ -68,12 +74,20 @@ def run_train_step(tr, batch: torch.Tensor, step: int, t: torch.Tensor = None, n
     loss = (acc / float(x.numel())).to(torch.float32).reshape(())
     d_eps = torch.empty_like(eps_hat)
     L.check(vdx_loss_grad(L.ptr(eps_hat), L.ptr(noise), L.ptr(d_eps), B, gd.channels, fhw, l2, L.stream_ptr()))
-    # reverse pass stage by stage; finished gradient buckets are all-reduced (RCCL) while earlier stages still run
+    # reverse pass in groups of stages that end where a gradient bucket becomes complete: finished buckets are all-reduced (RCCL)
+    # while earlier stages still run.  One call per group, not per stage: a call ends with the main stream waiting for the
+    # weight-gradient stream (vdx_unet_backward), which nothing needs between bucket boundaries -- and never on one GPU.
     reducer = tr.make_reducer()
     ns = unet.num_stages
-    for stage in range(ns - 1, -1, -1):
-        unet.backward(d_eps, tr.grads, stage, stage)
-        reducer.stage_done(stage)
+    cuts = sorted({min(max(b[2], 0), ns - 1) for b in tr.buckets} | {0}, reverse=True) if reducer.enabled else [0]
+    hi = ns - 1
+    for lo in cuts:
+        if lo > hi:
+            continue
+        unet.backward(d_eps, tr.grads, hi, lo)
+        for stage in range(hi, lo - 1, -1):
+            reducer.stage_done(stage)
+        hi = lo - 1
     reducer.finish()
     lr = tr.current_lr(tr.opt_count)                                               # schedule at the pre-increment count (B.2)
     do_ema = int(step >= tr.step_start_ema and step % tr.update_ema_every == 0)    # trainer.py:373-374
