@@ -122,6 +122,14 @@ int vdx_resblock_tail_rc_bf16(const void* y2, const void* x0, const void* x1, in
                               int groups, const float* ln_gamma, const float* ln_beta, int c, int batch, long pix_per_sample,
                               void* stream);
 
+/* Block prologue as its own pass, in place on a bf16 tensor (reference: modules.py:171-179, Block.__call__: GroupNorm, the
+ * time-embedding `x * (scale + 1) + shift`, SiLU): y <- SiLU(GroupNorm(y) * (scale + 1) + shift).  y bf16 channel-last
+ * [batch, pix_per_sample, c]; stats as the producing conv's epilogue leaves them (vdx_resblock_tail); scale_shift NULL (Block 2) or
+ * fp32 [batch][ss_stride] rows holding scale[c] | shift[c].  c a multiple of 8, c <= 1024.  The sampling forward runs it in front of
+ * the wide (c >= 256) second convs of bf16-storage networks. */
+int vdx_gn_silu_apply_bf16(void* y, const double* stats, const float* gn_gamma, const float* gn_beta, const float* scale_shift,
+                           int ss_stride, int groups, int c, int batch, long pix_per_sample, void* stream);
+
 /* init_conv (reference: unet3d.py:110-115,282): x EXTERNAL layout [B,Cin,F,H,W], Flax kernel (1,k,k,Cin,Cout) fp32,
  * y channel-last [B,F,H,W,Cout]. */
 int vdx_init_conv(const float* x, const float* kernel, const float* bias, float* y, int batch, int cin, int frames,

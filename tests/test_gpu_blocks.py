@@ -39,6 +39,28 @@ def test_resblock_tail(C, B, shape):
     assert _rel(out.cpu().double(), ref) < 2e-6
 
 
+@pytest.mark.parametrize('C,B,shape,ss', [(256, 2, (4, 8, 8), True), (512, 1, (16, 8, 8), True), (256, 3, (5, 16, 16), False), (64, 1, (3, 7, 5), True),
+                                         (1024, 1, (2, 4, 4), False), (24, 2, (1, 3, 3), True)])
+def test_block_prologue_pass_bf16(C, B, shape, ss):
+    """gn_silu_apply16_kernel (the sampling forward's pre-pass of the wide second convs) vs the oracle's GroupNorm / scale-shift / SiLU."""
+    from video_diffusion_nnx_amd import ops
+    g = torch.Generator().manual_seed(7 * C + B)
+    y = _bf(torch.randn(B, *shape, C, generator=g) * 1.5 + 0.3)
+    gg, gb = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    sc = 0.2 * torch.randn(B, 2 * C, generator=g) if ss else None
+    yg = y.double().reshape(B, -1, 8, C // 8)
+    stats = torch.zeros(B, 32, 8, 2, dtype=torch.float64)
+    stats[:, 0, :, 0] = yg.sum(dim=(1, 3)); stats[:, 0, :, 1] = (yg * yg).sum(dim=(1, 3))
+    out = ops.gn_silu_apply_bf16(y.to(DEV).to(torch.bfloat16).contiguous(), stats.reshape(-1).to(DEV), gg.to(DEV), gb.to(DEV),
+                                 None if sc is None else sc.to(DEV))
+    h = R.group_norm(y.double(), gg.double(), gb.double(), 8)
+    if ss:
+        bc = (B,) + (1,) * len(shape) + (C,)
+        h = h * (sc[:, :C].double().reshape(bc) + 1) + sc[:, C:].double().reshape(bc)
+    ref = R.silu(h)
+    assert _rel(out.float().cpu().double(), ref) < 4e-3          # one bf16 rounding of the result
+
+
 @pytest.mark.parametrize('c0,c1,C,B,shape', [(64, 64, 64, 2, (4, 16, 16)), (64, 0, 128, 1, (3, 8, 8)), (128, 128, 64, 2, (2, 8, 8)),
                                              (128, 0, 256, 1, (5, 4, 4)), (256, 0, 64, 1, (4, 32, 32)), (64, 64, 64, 3, (16, 64, 64)),
                                              (32, 32, 32, 2, (10, 16, 16)), (32, 0, 64, 1, (10, 8, 8)), (64, 64, 32, 1, (3, 8, 8))])   # dim-32 networks (config_v2_2 as written)

@@ -82,6 +82,7 @@ def stream_ptr() -> int:
 
 c_long = C.c_long
 vdx_resblock_tail = _sig('vdx_resblock_tail', c_int, [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p])
+vdx_gn_silu_apply_bf16 = _sig('vdx_gn_silu_apply_bf16', c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_int, c_long, c_void_p])
 vdx_resblock_tail_rc_bf16 = _sig('vdx_resblock_tail_rc_bf16', c_int, [c_void_p] * 3 + [c_int, c_int] + [c_void_p] * 6 + [c_int, c_void_p, c_void_p, c_int, c_int, c_long, c_void_p])
 vdx_init_conv = _sig('vdx_init_conv', c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p])
 vdx_final_conv = _sig('vdx_final_conv', c_int, [c_void_p] * 4 + [c_long, c_int, c_int, c_void_p])

@@ -167,6 +167,15 @@ int vdx_resblock_tail_rc_bf16(const void* y2, const void* x0, const void* x1, in
     return VDX_OK;
 }
 
+int vdx_gn_silu_apply_bf16(void* y, const double* stats, const float* gn_gamma, const float* gn_beta, const float* scale_shift,
+                           int ss_stride, int groups, int c, int batch, long pix_per_sample, void* stream) {
+    if (!y || !stats || !gn_gamma || !gn_beta) VDX_FAIL(VDX_ERR_INVALID, "gn_silu_apply: null tensor");
+    if (batch < 1 || pix_per_sample < 1 || c < 8 || c % 8 || c > 1024 || groups <= 0 || groups > 32 || c % groups || (scale_shift && ss_stride < 2 * c))
+        VDX_FAIL(VDX_ERR_INVALID, "gn_silu_apply: shape not served");
+    VDX_HIP(vdx::launch_gn_silu_apply16((float*)y, stats, gn_gamma, gn_beta, scale_shift, ss_stride, groups, c, batch, pix_per_sample, (hipStream_t)stream));
+    return VDX_OK;
+}
+
 int vdx_init_conv(const float* x, const float* kernel, const float* bias, float* y, int batch, int cin, int frames,
                   int h, int w, int cout, int k, void* stream) {
     if (!x || !kernel || !bias || !y) VDX_FAIL(VDX_ERR_INVALID, "init_conv: null tensor");

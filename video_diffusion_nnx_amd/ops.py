@@ -88,6 +88,16 @@ def resblock_tail_rc_bf16(y2, x0, x1, rc_kernel, rc_bias, stats, gn_gamma, gn_be
     return out
 
 
+def gn_silu_apply_bf16(y, stats, gn_gamma, gn_beta, scale_shift=None, groups=8):
+    """Block prologue in place on a bf16 tensor y [B,...,C]: SiLU(GroupNorm(y) * (scale + 1) + shift); scale_shift fp32 [B, 2C] or None."""
+    assert y.dtype == torch.bfloat16 and y.is_contiguous()
+    B, C = y.shape[0], y.shape[-1]
+    pix = y.numel() // (B * C)
+    L.check(L.vdx_gn_silu_apply_bf16(L.ptr(y), L.ptr(stats), L.ptr(gn_gamma), L.ptr(gn_beta), None if scale_shift is None else L.ptr(scale_shift),
+                                     0 if scale_shift is None else scale_shift.shape[-1], groups, C, B, pix, L.stream_ptr()))
+    return y
+
+
 def init_conv(x, kernel, bias):
     """x [B,C,F,H,W] (external layout); kernel Flax (1,k,k,C,D) -> [B,F,H,W,D]."""
     B, Cin, Fr, H, W = x.shape
