@@ -26,7 +26,7 @@ HBM_PEAK_GBS = 8000.0
 TRAFFIC_FILES = ('r03_traffic.json',)        # newest first; keyed by 'kernel | shape' (tools/traffic.sh)
 
 
-def time_kernels_in_step(run_eager, dev, steps=3):
+def time_kernels_in_step(run_eager, dev, steps=5):
     """Roofline leg: HIP-event duration of EVERY kernel launch INSIDE the real denoising step.  The library calls a hook before /
     after each launch (vdx_set_launch_hook, include/vdx.h) with the kernel's name, its template arguments + operand shape and the
     algorithmic FLOPs / bytes of that launch; the hook records a torch event on the launch stream, so each launch of `steps` eager
@@ -74,10 +74,14 @@ def time_kernels_in_step(run_eager, dev, steps=3):
         set_hook(C.cast(None, HOOK), None)
     per_key = {}
     for k, sh, fl, by, e0, e1 in records:
-        d = per_key.setdefault((k, sh), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-        d['ms'] += max(e0.elapsed_time(e1) - overhead_ms, 0.0) / steps; d['flops'] += fl / steps; d['bytes'] += by / steps; d['launches'] += 1
+        d = per_key.setdefault((k, sh), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, samples=[]))
+        d['samples'].append(max(e0.elapsed_time(e1) - overhead_ms, 0.0)); d['flops'] += fl / steps; d['bytes'] += by / steps; d['launches'] += 1
     for d in per_key.values():
+        # per-launch time of a row = the MEDIAN of its launches over the recorded steps (a row has >= `steps` samples): one stalled launch
+        # (a 5 ms hiccup was seen once on a shared box) must not make a 85 us kernel the step's "dominant" row
+        smp = sorted(d.pop('samples'))
         d['launches'] = d['launches'] // steps
+        d['ms'] = smp[len(smp) // 2] * d['launches']
     n = len(records) // steps
     sequence = [{'kernel': k, 'shape': sh, 'flops': fl, 'bytes': by} for k, sh, fl, by, _, _ in records[:n]]
     return per_key, sequence, overhead_ms * 1e3
@@ -257,7 +261,7 @@ def sampling_leg(args, dev, world, rank, dim, Fr, S, B, steps, warmup, roofline)
         torch.cuda.synchronize(dev)
         elapsed = time.perf_counter() - t0
         if rank == 0 and roofline:
-            log('roofline leg: events around every kernel launch of 3 eager steps of the same loop ...')
+            log('roofline leg: events around every kernel launch of 5 eager steps of the same loop ...')
             rec = time_kernels_in_step(lambda n: run(n, 0), dev)
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -416,8 +420,8 @@ def main():
                             'peak': HBM_PEAK_GBS if hb else MFMA_PEAK_TFLOPS[args.mode], 'unit': 'GB/s' if hb else 'TFLOP/s',
                             'frac': top['hbm_frac'] if hb else top['mfma_frac'], 'traffic': traffic, 'traffic_source': traffic_source,
                             'kernel': f"{top['kernel']} | {top['shape']}",
-                            'how': 'HIP events around EVERY kernel launch of 3 eager steps of the timed loop (library hook vdx_set_launch_hook), keyed by '
-                                   f'(kernel, template arguments + shape); empty event pair = {ev_overhead_us:.1f} us, subtracted; the row with the largest share of the step',
+                            'how': 'HIP events around EVERY kernel launch of 5 eager steps of the timed loop (library hook vdx_set_launch_hook), keyed by '
+                                   f'(kernel, template arguments + shape), per-launch time = the median of a row\'s launches; empty event pair = {ev_overhead_us:.1f} us, subtracted; the row with the largest share of the step',
                             **{k: top[k] for k in ('launches_per_step', 'avg_launch_us', 'gflop_per_launch', 'algorithmic_mb_per_launch',
                                                    'arithmetic_intensity_flop_per_byte', 'mfma_tflops', 'mfma_frac', 'hbm_gbs', 'hbm_frac', 'share_of_step')},
                             'bracketed_ms_per_step': sum(r['ms_per_step'] for r in rows),
