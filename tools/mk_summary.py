@@ -20,7 +20,7 @@ traffic = f"{rf['traffic']/1e6:.0f} MB per launch (PMC, committed `{tag}_traffic
 txt = f"""# Round 3 — profile summary (N shape: dim 64, 16 f × 64 × 64, B = 64 per GPU, bf16 operands + bf16 activation storage)
 
 Bench line of the profile box (`profiles/{tag}_bench_line.json`, `python bench.py`): **{d['value']:.2f} denoised frames/s, {d['ms_per_step']:.3f} ms per step** (boxes of
-the pool differ by ± 3 %: 20.2–21.4 ms were seen for the final code; the first half of the round ended at 21.9–22.6); Y shape {y['ms_per_step']:.2f} ms =
+the pool differ by ± 3 %: 20.2–20.9 ms were seen for the final code; the first half of the round ended at 21.9–22.6); Y shape {y['ms_per_step']:.2f} ms =
 {y['frames_per_s']:.1f} frames/s ({y['tflops']:.0f} TFLOP/s = {y['tflops']/y['n_shape_tflops']:.2f} of the N shape's {y['n_shape_tflops']:.0f}); training {trn['ms_per_step']:.2f} ms per step = {trn['samples_per_s']:.1f} samples/s
 (gradients bit-reproducible); CPU restatement {cb['value']:.4f} frames/s on {cb['cores']} cores ({cb['train']['value']:.2f} training samples/s);
 `other_configs`: configs[3] (dim 128, 32 f × 128², DDIM) {oc['configs3_f16']['ms_per_step']:.1f} ms per step at B = 1 with fp16 operands ({oc['configs3_bf16']['ms_per_step']:.1f} with bf16 operands + bf16 storage),
