@@ -298,6 +298,17 @@ PW_CASES = [
     (2, 16, 16, 256, 0, 256, True),    # level-2 attention / SLA to_out: + residual
     (9, 16, 8, 256, 0, 512, True),     # level-3 to_out, 9216 pixels: ragged pixel ranges
     (4, 8, 16, 128, 0, 192, True),     # one K block, three 64-row tiles
+    (2, 16, 32, 64, 0, 256, False),    # Cin = 64 (one 2-step K block per pixel group): the q / k / v projections the SLA backward recomputes at level 0
+    (1, 9, 32, 64, 0, 192, False),     # Cin = 64, 64-row tiles, 288 pixel groups (ragged ranges)
+    (1, 16, 32, 64, 0, 768, True),     # Cin = 64, six 128-row tiles, + residual
+]
+
+PW32_CASES = [
+    # B, F, S, Cin, Cout, res      (1x1, bf16 x, fp32 y and res: the dx projections of the attention / SLA backward)
+    (1, 16, 32, 768, 64, True),        # level 0: dq|dk|dv . [Wq;Wk;Wv]^T + g, one 64-row tile
+    (2, 16, 16, 768, 256, True),       # level 2: two 128-row tiles
+    (4, 16, 8, 768, 512, True),        # level 3
+    (2, 8, 32, 256, 128, False),       # no residual
 ]
 
 
@@ -329,6 +340,27 @@ def test_pointwise_conv_bf16(case):
     assert y.dtype == bf
     assert _rel(y.float().cpu().double(), ref) < 4e-3
     assert (y.float().cpu().double() - ref).abs().max() < 2e-2 * ref.abs().max()
+
+
+@pytest.mark.parametrize('case', PW32_CASES)
+def test_pointwise_conv_bf16_in_fp32_out(case):
+    """conv1x1_pw_kernel<ROWS, 4, OUT32>: bf16 input rows, fp32 output (+ fp32 residual) -- how the backward's dx projections run."""
+    from video_diffusion_nnx_amd import ops
+    dev = torch.device('cuda:0')
+    B, Fr, S, Cin, Cout, with_res = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(B, Fr, S, S, Cin, generator=g).to(torch.bfloat16)
+    kern = torch.randn(1, Cin, Cout, generator=g) / Cin ** 0.5
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, Fr, S, S, Cout, generator=g) if with_res else None
+    pw = ops.pack_conv_weights(kern.to(dev), 'bf16')
+    y = ops.conv_forward(x.to(dev), pw, Cout, mode='bf16', bias=bias.to(dev), k=1, y_bf16=False, res=None if res is None else res.to(dev))
+    torch.cuda.synchronize()
+    ref = x.double() @ _bf16r(kern[0]).double() + bias.double()
+    if with_res:
+        ref = ref + res.double()
+    assert y.dtype == torch.float32
+    assert _rel(y.cpu().double(), ref) < 3e-6                       # fp32 accumulation of exact bf16 products, no output rounding
 
 
 WS4_CASES = [

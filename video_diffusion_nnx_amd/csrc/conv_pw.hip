@@ -20,13 +20,17 @@ namespace vdx {
 
 typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
 
-// ROWS output channels per workgroup (64 or 128); K = Cin is a multiple of 128 (K blocks of 4 steps of 32)
-template <int ROWS>
+// ROWS output channels per workgroup (64 or 128); K = Cin in blocks of KS steps of 32: KS = 4 (Cin a multiple of 128) or KS = 2 (Cin = 64:
+// the q / k / v projections the SLA backward recomputes at the widest level -- one block per pixel group, so the NEXT GROUP's block is
+// in flight during the MFMAs); OUT32: y and res are fp32 tensors (the dx projections of the attention / SLA backward: bf16 dq|dk|dv in,
+// fp32 gradient out).
+template <int ROWS, int KS = 4, bool OUT32 = false>
 __global__ __launch_bounds__(512) void conv1x1_pw_kernel(const ConvArgs P, const int nct, const int groups_per_range, const int ngroups) {
     using M = Mma<MODE_BF16>;
     constexpr int TM = ROWS / 16, TN = 2;
+    constexpr int KBB = KS * 64;                           // bytes of one K block of a pixel row
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int Cin = P.C0 + P.C1, nkb = Cin >> 7;
+    const int Cin = P.C0 + P.C1, nkb = Cin / (32 * KS);
     const int WRS = Cin * 2 + 16;                          // LDS row stride of the weight image (bytes)
     char* Wl = smem;                                       // [ROWS, A-tile order][WRS]
     float* bl = reinterpret_cast<float*>(Wl + ROWS * WRS); // [ROWS] bias, channel order
@@ -52,16 +56,16 @@ __global__ __launch_bounds__(512) void conv1x1_pw_kernel(const ConvArgs P, const
 
     const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.x0), 0, P.x0_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(P.C1 ? P.x1 : P.x0), 0, P.C1 ? P.x1_bytes : P.x0_bytes, 0x00020000);
-    const int nkb0 = P.C0 >> 7;                            // K blocks in x0 (C0 is a multiple of 128 when there is a second tensor)
+    const int nkb0 = P.C0 / (32 * KS);                     // K blocks in x0 (C0 is a multiple of 128 when there is a second tensor)
     const unsigned rb0 = P.C0 * 2, rb1 = P.C1 * 2;
 
-    // one K block (4 steps x TN pixel tiles) of B fragments: 8 buffer loads, all issued before the first use
-    auto load_block = [&](int g, int kb, pu32x4 (&xf)[4][TN]) {
+    // one K block (KS steps x TN pixel tiles) of B fragments: 2 KS buffer loads, all issued before the first use
+    auto load_block = [&](int g, int kb, pu32x4 (&xf)[KS][TN]) {
         const bool second = kb >= nkb0;                    // (uniform)
         const unsigned rb = second ? rb1 : rb0;
-        const unsigned base = (unsigned)(g * 32 + lp) * rb + (unsigned)((second ? kb - nkb0 : kb) * 256 + q * 16);
+        const unsigned base = (unsigned)(g * 32 + lp) * rb + (unsigned)((second ? kb - nkb0 : kb) * KBB + q * 16);
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) {
                 const unsigned off = base + tn * 16 * rb + s * 64;
@@ -69,15 +73,15 @@ __global__ __launch_bounds__(512) void conv1x1_pw_kernel(const ConvArgs P, const
             }
     };
     f32x4 acc[TM][TN];
-    auto mma_block = [&](int kb, const pu32x4 (&xf)[4][TN]) {
+    auto mma_block = [&](int kb, const pu32x4 (&xf)[KS][TN]) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS; ++s) {
             uint4 bf[TN];
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) bf[tn] = make_uint4(xf[s][tn].x, xf[s][tn].y, xf[s][tn].z, xf[s][tn].w);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-                const uint4 af = *reinterpret_cast<const uint4*>(Wl + (tm * 16 + lp) * WRS + kb * 256 + s * 64 + q * 16);
+                const uint4 af = *reinterpret_cast<const uint4*>(Wl + (tm * 16 + lp) * WRS + kb * KBB + s * 64 + q * 16);
 #pragma unroll
                 for (int tn = 0; tn < TN; ++tn) M::mma(acc[tm][tn], af, bf[tn]);
             }
@@ -87,51 +91,82 @@ __global__ __launch_bounds__(512) void conv1x1_pw_kernel(const ConvArgs P, const
     char* const yb = reinterpret_cast<char*>(P.y);
     const char* const resb = reinterpret_cast<const char*>(P.res);
     // ROWS = 64: two fragment sets, the next K block's loads in flight during the MFMAs of the current one.  ROWS = 128 (64
-    // accumulator registers): one set -- the second would spill -- and the other wave of the SIMD covers the load latency
-    constexpr bool PP = ROWS == 64;
-    pu32x4 xa[4][TN], xb[PP ? 4 : 1][TN];
-    for (int g = g0 + wave; g < g1; g += 8) {
-        __asm__ volatile("" ::: "memory");                 // bias / weight fragments are re-read from LDS per group, not hoisted
+    // accumulator registers): one set -- the second would spill -- and the other wave of the SIMD covers the load latency.
+    // KS = 2 (one block per group): two sets, the next GROUP's block in flight.
+    constexpr bool PP = ROWS == 64 && KS == 4;
+    auto init_acc = [&]() {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const float4 b4 = *reinterpret_cast<const float4*>(bl + (tm >> 1) * 32 + q * 8 + (tm & 1) * 4);
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = f32x4{b4.x, b4.y, b4.z, b4.w};
         }
-        load_block(g, 0, xa);
-        if constexpr (PP) {
-            for (int kb = 0; kb < nkb; kb += 2) {
-                if (kb + 1 < nkb) load_block(g, kb + 1, xb);
-                mma_block(kb, xa);
-                if (kb + 1 >= nkb) break;
-                if (kb + 2 < nkb) load_block(g, kb + 2, xa);
-                mma_block(kb + 1, xb);
-            }
-        } else {
-            for (int kb = 0; kb < nkb; ++kb) {
-                mma_block(kb, xa);
-                if (kb + 1 < nkb) load_block(g, kb + 1, xa);
-            }
-        }
-        // epilogue: lane (pixel, q) holds channels co0 + 32 j + 8 q .. + 7 in acc[2 j][tn], acc[2 j + 1][tn]
+    };
+    // epilogue: lane (pixel, q) holds channels co0 + 32 j + 8 q .. + 7 in acc[2 j][tn], acc[2 j + 1][tn]
+    auto store_group = [&](int g) {
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const size_t pix = (size_t)g * 32 + tn * 16 + lp;
 #pragma unroll
             for (int j = 0; j < TM / 2; ++j) {
-                const size_t e = (pix * P.Cout + co0 + j * 32 + q * 8) * 2;
+                const size_t el = pix * P.Cout + co0 + j * 32 + q * 8;
                 float o[8];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { o[k] = acc[2 * j][tn][k]; o[4 + k] = acc[2 * j + 1][tn][k]; }
-                if (resb) {
-                    const uint4 r = *reinterpret_cast<const uint4*>(resb + e);
-                    o[0] += __uint_as_float(r.x << 16); o[1] += __uint_as_float(r.x & 0xFFFF0000u);
-                    o[2] += __uint_as_float(r.y << 16); o[3] += __uint_as_float(r.y & 0xFFFF0000u);
-                    o[4] += __uint_as_float(r.z << 16); o[5] += __uint_as_float(r.z & 0xFFFF0000u);
-                    o[6] += __uint_as_float(r.w << 16); o[7] += __uint_as_float(r.w & 0xFFFF0000u);
+                if constexpr (OUT32) {
+                    if (resb) {
+                        const float4 r0 = *reinterpret_cast<const float4*>(resb + el * 4), r1 = *reinterpret_cast<const float4*>(resb + el * 4 + 16);
+                        o[0] += r0.x; o[1] += r0.y; o[2] += r0.z; o[3] += r0.w; o[4] += r1.x; o[5] += r1.y; o[6] += r1.z; o[7] += r1.w;
+                    }
+                    *reinterpret_cast<float4*>(yb + el * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                    *reinterpret_cast<float4*>(yb + el * 4 + 16) = make_float4(o[4], o[5], o[6], o[7]);
+                } else {
+                    const size_t e = el * 2;
+                    if (resb) {
+                        const uint4 r = *reinterpret_cast<const uint4*>(resb + e);
+                        o[0] += __uint_as_float(r.x << 16); o[1] += __uint_as_float(r.x & 0xFFFF0000u);
+                        o[2] += __uint_as_float(r.y << 16); o[3] += __uint_as_float(r.y & 0xFFFF0000u);
+                        o[4] += __uint_as_float(r.z << 16); o[5] += __uint_as_float(r.z & 0xFFFF0000u);
+                        o[6] += __uint_as_float(r.w << 16); o[7] += __uint_as_float(r.w & 0xFFFF0000u);
+                    }
+                    *reinterpret_cast<uint4*>(yb + e) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
                 }
-                *reinterpret_cast<uint4*>(yb + e) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7]));
             }
+        }
+    };
+    if constexpr (KS == 2) {
+        pu32x4 xa[KS][TN], xb[KS][TN];
+        int g = g0 + wave;
+        if (g < g1) load_block(g, 0, xa);
+        for (; g < g1; g += 16) {
+            __asm__ volatile("" ::: "memory");             // bias / weight fragments are re-read from LDS per group, not hoisted
+            if (g + 8 < g1) load_block(g + 8, 0, xb);
+            init_acc(); mma_block(0, xa); store_group(g);
+            if (g + 8 >= g1) break;
+            if (g + 16 < g1) load_block(g + 16, 0, xa);
+            init_acc(); mma_block(0, xb); store_group(g + 8);
+        }
+    } else {
+        pu32x4 xa[KS][TN], xb[PP ? KS : 1][TN];
+        for (int g = g0 + wave; g < g1; g += 8) {
+            __asm__ volatile("" ::: "memory");             // bias / weight fragments are re-read from LDS per group, not hoisted
+            init_acc();
+            load_block(g, 0, xa);
+            if constexpr (PP) {
+                for (int kb = 0; kb < nkb; kb += 2) {
+                    if (kb + 1 < nkb) load_block(g, kb + 1, xb);
+                    mma_block(kb, xa);
+                    if (kb + 1 >= nkb) break;
+                    if (kb + 2 < nkb) load_block(g, kb + 2, xa);
+                    mma_block(kb + 1, xb);
+                }
+            } else {
+                for (int kb = 0; kb < nkb; ++kb) {
+                    mma_block(kb, xa);
+                    if (kb + 1 < nkb) load_block(g, kb + 1, xa);
+                }
+            }
+            store_group(g);
         }
     }
 }
@@ -145,9 +180,13 @@ int conv1x1_pw_rows(const ConvArgs& a) {
 
 bool conv1x1_pw_eligible(int mode, const ConvArgs& a) {
     if (mode != MODE_BF16 || a.kind != 0 || a.kh != 1 || a.kw != 1 || a.stride != 1 || a.pad != 0 || a.pro || a.out_stats) return false;
-    if (!a.x0_bf16 || (a.C1 && !a.x1_bf16) || !a.y_bf16 || (a.res && !a.res_bf16)) return false;
+    if (!a.x0_bf16 || (a.C1 && !a.x1_bf16)) return false;
+    const bool out32 = !a.y_bf16;                          // fp32 y (+ fp32 res): the dx projections of the attention / SLA backward
+    if (a.res && (a.res_bf16 != 0) == out32) return false;
     const int cin = a.C0 + a.C1;
-    if (cin % 128 || cin > 1024 || a.Cout % 64 || a.Cout < 128) return false;
+    if ((cin % 128 && cin != 64) || cin > 1024 || a.Cout % 64 || a.Cout < 64) return false;
+    if (out32 && cin == 64) return false;                   // (no such launch)
+    if (!out32 && cin != 64 && a.Cout < 128) return false;  // (64-channel bf16 outputs of the forward stay where they were measured)
     if (a.C1 && (a.C0 % 128 || a.C1 % 128)) return false;
     if (a.CinPad != cin) return false;
     const size_t npix = (size_t)a.NF * a.H * a.W;
@@ -179,6 +218,8 @@ hipError_t launch_conv1x1_pw(const ConvArgs& a, hipStream_t st) {
         hipLaunchKernelGGL(kfn, dim3(nranges * nct), dim3(512), lds, st, a, nct, gpr, ngroups);
         return hipGetLastError();
     };
+    if (!a.y_bf16) return rows == 128 ? go(conv1x1_pw_kernel<128, 4, true>) : go(conv1x1_pw_kernel<64, 4, true>);
+    if (cin == 64) return rows == 128 ? go(conv1x1_pw_kernel<128, 2>) : go(conv1x1_pw_kernel<64, 2>);
     return rows == 128 ? go(conv1x1_pw_kernel<128>) : go(conv1x1_pw_kernel<64>);
 }
 
