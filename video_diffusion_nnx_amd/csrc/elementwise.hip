@@ -204,7 +204,9 @@ hipError_t launch_gn_silu_apply16(float* y_bf16, const double* stats, const floa
 // offset per tensor + immediates.  CAT: the input is a concat of two CIN/2-channel tensors.
 typedef unsigned tu32x4 __attribute__((ext_vector_type(4)));
 
-template <int CIN, int COUT, bool CAT>
+// FIN: the network's 1x1 head (one output channel) instead of the store of `out`: the last block's output never exists in HBM (537 MB
+// written and read again at the N shape, B = 64) and `final_conv16_kernel` is not launched; the dot product takes the fp32 values.
+template <int CIN, int COUT, bool CAT, bool FIN = false>
 __global__ __launch_bounds__(256, (CIN == 128 && COUT == 64) ? 4 : (COUT <= 128 ? 3 : 2)) void resblock_tail_rc16_kernel(TailArgs P) {
     using M = Mma<MODE_BF16>;
     constexpr int NTM = COUT / 16, NKS = CIN / 32, NH = COUT / 32;
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256, (CIN == 128 && COUT == 64) ? 4 : (COUT <= 128 
     float* lnb = lng + COUT;
     float* rcb = lnb + COUT;
     float* gm = rcb + COUT;                                 // [32][mean, rstd]
+    float* finw = gm + 64;                                  // [COUT] (FIN)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lp = lane & 15, q = lane >> 4;
     const int b = blockIdx.y;
     for (int i = tid; i < COUT * (CIN / 8); i += 256) {
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(256, (CIN == 128 && COUT == 64) ? 4 : (COUT <= 128 
         coefA[c] = a;
         coefD[c] = P.gn_beta[c] - gm[2 * g] * a;
         lng[c] = P.ln_gamma[c]; lnb[c] = P.ln_beta[c]; rcb[c] = P.rc_b[c];
+        if (FIN) finw[c] = P.fin_w[c];
     }
     __syncthreads();
 
@@ -242,7 +246,9 @@ __global__ __launch_bounds__(256, (CIN == 128 && COUT == 64) ? 4 : (COUT <= 128 
     const char* x0p = reinterpret_cast<const char*>(P.x0) + (size_t)b * pps * C0 * 2;
     const char* x1p = CAT ? reinterpret_cast<const char*>(P.x1) + (size_t)b * pps * C0 * 2 : x0p;
     const char* y2p = reinterpret_cast<const char*>(P.y2) + (size_t)b * pps * COUT * 2;
-    char* outp = reinterpret_cast<char*>(P.out) + (size_t)b * pps * COUT * 2;
+    char* outp = FIN ? const_cast<char*>(y2p) : reinterpret_cast<char*>(P.out) + (size_t)b * pps * COUT * 2;      // (FIN: no store through `ro`)
+    float* const finp = FIN ? P.fin_out + (size_t)b * pps : nullptr;
+    const float finb = FIN ? P.fin_b[0] : 0.f;
     const __amdgpu_buffer_rsrc_t rx0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x0p), 0, pps * C0 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(x1p), 0, pps * C0 * 2, 0x00020000);
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(y2p), 0, pps * COUT * 2, 0x00020000);
@@ -287,6 +293,7 @@ __global__ __launch_bounds__(256, (CIN == 128 && COUT == 64) ? 4 : (COUT <= 128 
         const float var = fmaxf(s2 * (1.0f / COUT) - mean * mean, 0.f);
         const float rstd = rsqrtf(var + NORM_EPS);
         const unsigned oy = (unsigned)g * (16 * COUT * 2) + lane_y;
+        float dot = 0.f;
 #pragma unroll
         for (int j = 0; j < NH; ++j) {
             float y[8], o[8];
@@ -302,8 +309,18 @@ __global__ __launch_bounds__(256, (CIN == 128 && COUT == 64) ? 4 : (COUT <= 128 
                 o[4 * h + 2] = silu_f(fmaf(y[4 * h + 2], a4.z, d4.z)) + fmaf((r[2] - mean) * rstd, g4.z, e4.z);
                 o[4 * h + 3] = silu_f(fmaf(y[4 * h + 3], a4.w, d4.w)) + fmaf((r[3] - mean) * rstd, g4.w, e4.w);
             }
-            __builtin_amdgcn_raw_buffer_store_b128(tu32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])},
-                                                   ro, oy + j * 64, 0, 0);
+            if constexpr (FIN) {
+                const float4 w0 = *reinterpret_cast<const float4*>(finw + c0), w1 = *reinterpret_cast<const float4*>(finw + c0 + 4);
+                dot = fmaf(o[0], w0.x, dot); dot = fmaf(o[1], w0.y, dot); dot = fmaf(o[2], w0.z, dot); dot = fmaf(o[3], w0.w, dot);
+                dot = fmaf(o[4], w1.x, dot); dot = fmaf(o[5], w1.y, dot); dot = fmaf(o[6], w1.z, dot); dot = fmaf(o[7], w1.w, dot);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(tu32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])},
+                                                       ro, oy + j * 64, 0, 0);
+            }
+        }
+        if constexpr (FIN) {
+            dot = reduce_q(dot);                                 // the 4 lanes (q) of a pixel
+            if (q == 0) finp[(size_t)g * 16 + lp] = dot + finb;
         }
     };
 
@@ -329,7 +346,7 @@ bool tail_rc16_supported(int cin, int c0, int cout, long pix_per_sample) {
 
 template <int CIN, int COUT>
 static hipError_t launch_tail_rc16(const TailArgs& a, hipStream_t st) {
-    const size_t lds = (size_t)COUT * (CIN * 2 + 16) + (5 * COUT + 64) * sizeof(float);
+    const size_t lds = (size_t)COUT * (CIN * 2 + 16) + (6 * COUT + 64) * sizeof(float);
     // every workgroup starts with the weight image + the statistics -> coefficient chain: ~8 passes of 4 x 16 pixels each, but at
     // least ~2048 workgroups in the launch
     const long need = (a.pix_per_sample / 16 + 3) / 4;
@@ -340,11 +357,15 @@ static hipError_t launch_tail_rc16(const TailArgs& a, hipStream_t st) {
             if (e != hipSuccess) return e;
         }
         const double px = (double)a.batch * a.pix_per_sample;       // y2, x (concat) in + out, bf16; the 1x1 res_conv on the MFMA
-        LaunchScope ls(st, "resblock_tail_rc16_kernel", 2.0 * px * CIN * COUT, px * (CIN + 2.0 * COUT) * 2 + 2.0 * CIN * COUT, "<%d, %d, %s> px%ld x %d", CIN, COUT,
-                       a.C1 ? "true" : "false", a.pix_per_sample, a.batch);
+        LaunchScope ls(st, "resblock_tail_rc16_kernel", 2.0 * px * CIN * COUT + (a.fin_w ? 2.0 * px * COUT : 0.0),
+                       px * (CIN + (a.fin_w ? 1.0 : 2.0) * COUT) * 2 + (a.fin_w ? px * 4 : 0.0) + 2.0 * CIN * COUT, "<%d, %d, %s> px%ld x %d", CIN, COUT,
+                       a.fin_w ? "true, head" : (a.C1 ? "true" : "false"), a.pix_per_sample, a.batch);
         hipLaunchKernelGGL(kfn, dim3((unsigned)gx, a.batch), dim3(256), lds, st, a);
         return hipGetLastError();
     };
+    if constexpr ((CIN == 128 && COUT == 64) || (CIN == 64 && COUT == 32)) {      // (the last block of a dim-64 / dim-32 network: a concat)
+        if (a.fin_w) return a.C1 ? go(resblock_tail_rc16_kernel<CIN, COUT, true, true>) : hipErrorInvalidValue;
+    } else if (a.fin_w) return hipErrorInvalidValue;
     return a.C1 ? go(resblock_tail_rc16_kernel<CIN, COUT, true>) : go(resblock_tail_rc16_kernel<CIN, COUT, false>);
 }
 

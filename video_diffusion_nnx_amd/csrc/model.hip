@@ -346,11 +346,16 @@ struct Fwd {
     double* stat(int i) const { return stats + (size_t)i * B * GN_SLOTS * m->cfg.resnet_groups * 2; }
 };
 
+#ifndef VDX_FUSE_HEAD
+#define VDX_FUSE_HEAD 1                                      // final 1x1 conv (one output channel) inside the last block's tail (inference storage)
+#endif
 #ifndef VDX_PREPASS_MIN_C
 #define VDX_PREPASS_MIN_C 256                                 // Block prologue as its own pass from this width on (sampling forward)
 #endif
 
-static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, const float* x1, int c1, int lvl) {
+// head_out: (the network's last block) write head_out[pix] = out[pix][:] . fin_w + fin_b instead of the block's output when the tail form
+// that can do it runs (*head_done = true), else the caller launches the final conv as before
+static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, const float* x1, int c1, int lvl, float* head_out = nullptr, bool* head_done = nullptr) {
     const Model* m = f.m;
     const int G = m->cfg.resnet_groups;
     const int S = m->cfg.image_size >> lvl;
@@ -406,6 +411,10 @@ static hipError_t run_res(const Fwd& f, const ResP& r, const float* x0, int c0, 
     t.ln_gamma = f.p + r.n2_s; t.ln_beta = f.p + r.n2_b;
     t.C = r.cout; t.batch = f.B; t.pix_per_sample = (long)m->cfg.num_frames * S * S;
     if (fuse_rc) { t.x0 = x0; t.x1 = x1; t.C0 = c0; t.C1 = c1; t.rc_w = f.pk + r.pk_rc; t.rc_b = f.p + r.rc_b; }
+    if (VDX_FUSE_HEAD && head_out && fuse_rc && c1 == c0 && m->out_dim == 1 && ((c0 + c1 == 128 && r.cout == 64) || (c0 + c1 == 64 && r.cout == 32))) {
+        t.fin_w = f.p + m->fin_w; t.fin_b = f.p + m->fin_b; t.fin_out = head_out;
+        *head_done = true;
+    }
     return launch_resblock_tail(t, f.st);
 }
 
@@ -570,8 +579,9 @@ int model_forward(const Model* m, const float* params, const void* packed, const
         cur = f.slot(L.s_attn); cur_c = L.cout;
         if (L.has_resample) { VDX_E(run_resample(f, L, cur, f.slot(L.s_rs), L.lvl, true)); cur = f.slot(L.s_rs); }
     }
-    VDX_E(run_res(f, m->fin, cur, cur_c, f.slot(m->s_init_attn), m->init_dim, 0));                // unet3d.py:377-382
-    VDX_E(launch_final_conv(f.slot(m->fin.s_out), params + m->fin_w, params + m->fin_b, out, (long)B * Fr * S0 * S0, c.dim, m->out_dim, f.a16, st));
+    bool head_done = false;                                  // (sampling forward: the 1-channel head inside the last block's tail)
+    VDX_E(run_res(f, m->fin, cur, cur_c, f.slot(m->s_init_attn), m->init_dim, 0, out, &head_done));                // unet3d.py:377-382
+    if (!head_done) VDX_E(launch_final_conv(f.slot(m->fin.s_out), params + m->fin_w, params + m->fin_b, out, (long)B * Fr * S0 * S0, c.dim, m->out_dim, f.a16, st));
 #undef VDX_E
     return VDX_OK;
 }

@@ -74,6 +74,9 @@ struct TailArgs {
     const float* x0; const float* x1; int C0, C1;
     const void* rc_w;               // packed [C rows][C0 + C1] bf16 (conv_packed_bytes(MODE_BF16, 1, C0 + C1, C)), or null
     const float* rc_b;              // [C]
+    // fused head (sampling forward, the network's last block): fin_out[pix][0] = out[pix][:] . fin_w[:][0] + fin_b[0] is written INSTEAD of
+    // `out` (final_conv of unet3d.py:251 with one output channel; `out` may be null then)
+    const float* fin_w; const float* fin_b; float* fin_out;
 };
 // shapes resblock_tail_rc16_kernel is instantiated for
 bool tail_rc16_supported(int cin, int c0, int cout, long pix_per_sample);
